@@ -1,0 +1,612 @@
+#!/usr/bin/env python3
+"""Golden-vector generator for the intercept-environment hot path.
+
+Runs ONLY in the build container (needs /root/reference); its outputs
+(tests/golden/*.npz) are plain data and are what travels to the GPU box.
+
+What it does
+------------
+* registers an in-memory `gymnasium` stand-in (only `Env` and `spaces.Box` are touched by
+  the reference: rl_system/environment.py:6-7,15,192-197,355), imports the reference's
+  `InterceptEnvironment` read-only (no bytecode is written),
+* wraps the three random streams of the path with recorders so every variate the reference
+  consumes is captured as a *unit* draw (U(0,1), N(0,1), Exp(1)) in a fixed slot layout
+  (SURVEY.md §8 a21); the wrappers return bit-identical values to the unwrapped calls
+  (checked by `_selfcheck_wrappers`),
+* drives a list of cases (scenario x physics x observation mode x reward mode + forced edge
+  cases), with VecEnv-style auto-reset, and dumps per step: action, noise slots, post-step
+  state (incl. Kalman state/covariance and delay-ring bookkeeping), obs[26], reward, flags.
+
+Slot layout (kept in sync with include/hlx.h HLX_SLOT_*):
+  step : 0-2 evasion N | 3-5 wind N | 6 gust U | 7-9 gust dir N | 10 gust mag Exp
+         11 onboard U | 12 ground U | 13-15 ground pos N | 16-18 ground vel N | 19 datalink U
+  reset: 0-2 missile pos U (box) or radius/azimuth/elevation U (spherical) | 3 missile speed U
+         4-6 interceptor pos U | 7-9 interceptor vel U (box) or 7 speed U (toward_missile)
+         10 onboard U | 11 ground U | 12-14 ground pos N | 15-17 ground vel N | 18 datalink U
+         19-31 domain-randomisation N x13
+Unused slots hold NaN.
+"""
+import sys
+import types
+import json
+import copy
+import os
+
+sys.dont_write_bytecode = True
+import numpy as np
+import yaml
+
+REF = "/root/reference/rl_system"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+N_STEP_SLOTS = 20
+N_RESET_SLOTS = 32
+
+
+# --------------------------------------------------------------------------------------
+# gymnasium stand-in (in memory only)
+# --------------------------------------------------------------------------------------
+def _install_gym_shim():
+    gym = types.ModuleType("gymnasium")
+    spaces = types.ModuleType("gymnasium.spaces")
+
+    class Env:
+        metadata = {}
+
+        def reset(self, seed=None, options=None):
+            return None
+
+    class Box:
+        def __init__(self, low, high, shape, dtype):
+            self.low, self.high, self.shape, self.dtype = low, high, shape, dtype
+
+    gym.Env = Env
+    spaces.Box = Box
+    gym.spaces = spaces
+    sys.modules["gymnasium"] = gym
+    sys.modules["gymnasium.spaces"] = spaces
+
+
+# --------------------------------------------------------------------------------------
+# RNG recorders
+# --------------------------------------------------------------------------------------
+class Tape:
+    """Collects the unit draws of the current step / reset into slot arrays."""
+
+    def __init__(self):
+        self.mode = "reset"
+        self.clear()
+
+    def clear(self):
+        self.step = np.full(N_STEP_SLOTS, np.nan)
+        self.reset = np.full(N_RESET_SLOTS, np.nan)
+        self._reset_uniform_calls = 0
+        self._ground_normal_calls = 0
+        self._wind_normal_calls = 0
+        self._dr_calls = 0
+
+    def put(self, where, start, vals):
+        arr = self.step if where == "step" else self.reset
+        vals = np.atleast_1d(np.asarray(vals, dtype=np.float64))
+        assert np.all(np.isnan(arr[start:start + len(vals)])), (where, start, "slot written twice")
+        arr[start:start + len(vals)] = vals
+
+
+TAPE = Tape()
+_orig_default_rng = np.random.default_rng
+_orig_uniform = np.random.uniform
+_orig_randn = np.random.randn
+
+
+def _caller(depth=2):
+    return sys._getframe(depth).f_code.co_name
+
+
+class RecGen:
+    """Proxy for numpy.random.Generator: draws unit variates from the real generator,
+    records them and applies loc/scale exactly as numpy's C code does (loc + scale * z)."""
+
+    def __init__(self, gen):
+        self._g = gen
+
+    def random(self):
+        u = self._g.random()
+        who = _caller()
+        if who == "compute_radar_detection":
+            TAPE.put(*(("step", 11) if TAPE.mode == "step" else ("reset", 10)), u)
+        elif who == "_compute_ground_radar_detection":
+            TAPE.put(*(("step", 12) if TAPE.mode == "step" else ("reset", 11)), u)
+        elif who == "_compute_datalink_quality":
+            TAPE.put(*(("step", 19) if TAPE.mode == "step" else ("reset", 18)), u)
+        elif who == "get_wind_vector":
+            TAPE.put("step", 6, u)
+        elif who == "randomize_for_episode":
+            pass  # the 'timestamp' draw; has no effect on the path
+        else:
+            raise RuntimeError("unexpected random() caller " + who)
+        return u
+
+    def normal(self, loc=0.0, scale=1.0, size=None):
+        z = self._g.standard_normal(size)
+        who = _caller()
+        if who == "_compute_ground_radar_detection":
+            k = TAPE._ground_normal_calls
+            TAPE._ground_normal_calls += 1
+            base = (13 if TAPE.mode == "step" else 12) + 3 * k
+            TAPE.put(TAPE.mode, base, z)
+        elif who == "get_wind_vector":
+            k = TAPE._wind_normal_calls
+            TAPE._wind_normal_calls += 1
+            TAPE.put("step", 3 if k == 0 else 7, z)
+        elif who in ("randomize_for_episode", "_randomize_multiplier"):
+            TAPE.put("reset", 19 + TAPE._dr_calls, z)
+            TAPE._dr_calls += 1
+        else:
+            raise RuntimeError("unexpected normal() caller " + who)
+        return loc + scale * z
+
+    def exponential(self, scale=1.0):
+        e = self._g.standard_exponential()
+        assert _caller() == "get_wind_vector"
+        TAPE.put("step", 10, e)
+        return scale * e
+
+
+def _rec_default_rng(seed=None):
+    return RecGen(_orig_default_rng(seed))
+
+
+def _rec_uniform(low=0.0, high=1.0, size=None):
+    who = _caller()
+    assert who == "reset", who
+    low_a, high_a = np.asarray(low, dtype=np.float64), np.asarray(high, dtype=np.float64)
+    shape = np.broadcast(low_a, high_a).shape
+    u = np.random.random_sample(shape if shape else None)
+    k = TAPE._reset_uniform_calls
+    TAPE._reset_uniform_calls += 1
+    TAPE._uniform_log.append((k, np.atleast_1d(u).copy()))
+    val = low_a + (high_a - low_a) * u
+    # numpy returns a Python float for the scalar call (weak in NEP-50 promotion): keep that
+    return float(val) if shape == () else val
+
+
+def _rec_randn(*shape):
+    z = np.random.standard_normal(shape)
+    who = _caller()
+    if who == "_update_missile_state":
+        TAPE.put("step", 0, z)
+    elif who == "_update_wind":
+        TAPE.put("step", 3, z)
+    else:
+        raise RuntimeError("unexpected randn caller " + who)
+    return z
+
+
+def _selfcheck_wrappers():
+    st = np.random.get_state()
+    a = _orig_uniform([1, 2, 3], [4, 6, 9])
+    b = _orig_uniform(3.0, 7.5)
+    c = _orig_randn(3)
+    np.random.set_state(st)
+    TAPE._uniform_log = []
+    frame_reset = lambda: None  # noqa: E731
+
+    def reset():  # name matters: the wrappers assert on their caller's name
+        return _rec_uniform([1, 2, 3], [4, 6, 9]), _rec_uniform(3.0, 7.5)
+
+    def _update_missile_state():
+        return _rec_randn(3)
+
+    a2, b2 = reset()
+    c2 = _update_missile_state()
+    assert np.array_equal(a, a2) and b == b2 and np.array_equal(c, c2), "global-stream wrappers not bit-identical"
+    g1, g2 = _orig_default_rng(7), RecGen(_orig_default_rng(7))
+    x1 = g1.normal(1.0, 0.3)
+
+    def randomize_for_episode():
+        return g2.normal(1.0, 0.3)
+
+    TAPE.clear()
+    assert x1 == randomize_for_episode(), "Generator.normal wrapper not bit-identical"
+    x1 = g1.normal(0, 2.5, 3)
+
+    def get_wind_vector():
+        return g2.normal(0, 2.5, 3), g2.exponential(5.0)
+
+    TAPE.clear()
+    TAPE.mode = "step"
+    y, e = get_wind_vector()
+    assert np.array_equal(x1, y) and e == g1.exponential(5.0)
+    TAPE.clear()
+
+
+# --------------------------------------------------------------------------------------
+# state capture
+# --------------------------------------------------------------------------------------
+def ring_dump(buf, width, getter):
+    """Logical (oldest -> newest) contents of a SensorDelayBuffer."""
+    if buf is None:
+        return dict(delay=0, count=0, data=np.zeros((0, width)), det=np.zeros(0, np.int32))
+    data = np.zeros((len(buf.measurement_buffer), width))
+    for i, m in enumerate(buf.measurement_buffer):
+        data[i] = getter(m)
+    return dict(delay=buf.delay_samples, count=buf.samples_received, data=data,
+                det=np.array(list(buf.detection_buffer), dtype=np.int32))
+
+
+def capture_state(env):
+    og = env.observation_generator
+    kf = og.kalman_filter
+    ist, mst = env.interceptor_state, env.missile_state
+    s = dict(
+        int_pos=np.array(ist["position"], np.float64), int_vel=np.array(ist["velocity"], np.float64),
+        int_quat=np.array(ist["orientation"], np.float64), fuel=np.float64(ist["fuel"]),
+        mis_pos=np.array(mst["position"], np.float64), mis_vel=np.array(mst["velocity"], np.float64),
+        wind=np.array(env.current_wind, np.float64),
+        thrust_actual=np.array(getattr(env, "interceptor_thrust_actual", np.zeros(3)), np.float64),
+        steps=np.int64(env.steps),
+        prev_distance=np.float64(env._prev_distance), min_distance=np.float64(env._episode_min_distance),
+        last_distance=np.float64(env._last_distance), worsening=np.int64(env._distance_worsening_count),
+        crossed=np.int64(bool(env._crossed_threshold)),
+        kf_init=np.int64(bool(kf.initialized)), kf_x=np.array(kf.state, np.float64),
+        kf_x_is64=np.int64(kf.state.dtype == np.float64), kf_P=np.array(kf.P, np.float64),
+        total_fuel_used=np.float64(env.total_fuel_used),
+    )
+    on = ring_dump(og.sensor_delay_buffer, 3, lambda m: m["rel_pos"])
+    gr = ring_dump(og.ground_sensor_delay_buffer, 7,
+                   lambda m: np.concatenate([m["rel_pos"], m["rel_vel"], [m["quality"]]]))
+    s.update(on_delay=np.int64(on["delay"]), on_count=np.int64(on["count"]), on_ring=on["data"], on_det=on["det"],
+             g_delay=np.int64(gr["delay"]), g_count=np.int64(gr["count"]), g_ring=gr["data"])
+    if env.atmospheric_model is not None:
+        s["T0"] = np.float64(env.atmospheric_model.constants.SEA_LEVEL_TEMPERATURE)
+    else:
+        s["T0"] = np.float64(288.15)
+    if env.mach_drag_model is not None:
+        s["base_cd"] = np.float64(env.mach_drag_model.base_cd)
+        s["transonic_peak"] = np.float64(env.mach_drag_model.transonic_peak_multiplier)
+    else:
+        s["base_cd"], s["transonic_peak"] = np.float64(0.3), np.float64(3.0)
+    return s
+
+
+def stack_states(states):
+    keys = states[0].keys()
+    out = {}
+    for k in keys:
+        vals = [s[k] for s in states]
+        if k in ("on_ring", "g_ring", "on_det"):
+            # ragged during ring warm-up: pad to the max depth with NaN / -1
+            depth = max(v.shape[0] for v in vals)
+            width = vals[0].shape[1] if vals[0].ndim == 2 else None
+            if width is None:
+                pad = np.full((len(vals), depth), -1, np.int32)
+                for i, v in enumerate(vals):
+                    pad[i, :len(v)] = v
+            else:
+                pad = np.full((len(vals), depth, width), np.nan)
+                for i, v in enumerate(vals):
+                    pad[i, :v.shape[0]] = v
+            out[k] = pad
+        else:
+            out[k] = np.stack(vals)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# case running
+# --------------------------------------------------------------------------------------
+def load_yaml(rel):
+    with open(os.path.join(REF, rel)) as f:
+        return yaml.safe_load(f)
+
+
+def scenario_config(name, physics="config", overrides=None, base="config.yaml"):
+    """Env config the way the specialist trainer / offline inference build it:
+    config.yaml `environment` shallow-updated by the scenario's `environment`
+    (rl_system/inference.py:383-390), `curriculum` and `physics_enhancements` merged in
+    (rl_system/scripts/train_hrl_pretrain.py:335-338)."""
+    cfg = load_yaml(base)
+    env_cfg = copy.deepcopy(cfg["environment"])
+    if name is not None:
+        env_cfg.update(copy.deepcopy(load_yaml(f"configs/scenarios/{name}.yaml")["environment"]))
+    if physics == "config":
+        env_cfg["curriculum"] = copy.deepcopy(cfg.get("curriculum", {}))
+        env_cfg["physics_enhancements"] = copy.deepcopy(cfg.get("physics_enhancements", {}))
+    elif physics == "base":
+        env_cfg["curriculum"] = copy.deepcopy(cfg.get("curriculum", {}))
+        env_cfg["physics_enhancements"] = {"enabled": False}
+    elif physics == "v2":
+        # constructor defaults = everything on (what train_flat_ppo.py:369 effectively runs)
+        env_cfg["curriculum"] = copy.deepcopy(cfg.get("curriculum", {}))
+        env_cfg["physics_enhancements"] = {"enabled": True}
+    elif physics == "v2dr":
+        env_cfg["curriculum"] = copy.deepcopy(cfg.get("curriculum", {}))
+        pe = copy.deepcopy(cfg.get("physics_enhancements", {}))
+        for k in ("atmospheric_model", "sensor_delays", "mach_effects", "thrust_dynamics", "enhanced_wind",
+                  "domain_randomization"):
+            pe[k]["enabled"] = True
+        env_cfg["physics_enhancements"] = pe
+    elif physics == "flat":
+        pass  # train_flat_ppo.py:369 - only `environment`, env falls back to ctor defaults
+    else:
+        raise ValueError(physics)
+    for path, val in (overrides or {}).items():
+        d = env_cfg
+        keys = path.split(".")
+        for k in keys[:-1]:
+            d = d.setdefault(k, {})
+        d[keys[-1]] = val
+    return env_cfg
+
+
+def pursuit_action(env, rng, gain=1.0, jitter=0.2):
+    """Crude pursuit controller so that intercepts actually occur in some cases."""
+    rel = env.missile_state["position"] - env.interceptor_state["position"]
+    closing = env.missile_state["velocity"] - env.interceptor_state["velocity"]
+    tgo = np.clip(np.linalg.norm(rel) / (np.linalg.norm(closing) + 1e-3), 0.05, 5.0)
+    aim = rel + closing * tgo
+    a = np.zeros(6, np.float32)
+    d = aim / (np.linalg.norm(aim) + 1e-6)
+    d[2] += 0.25  # fight gravity
+    if env.observation_mode == "los_frame":
+        a[0:3] = [gain, 0.0, 0.3]
+    else:
+        a[0:3] = np.clip(gain * d, -1, 1)
+    a[3:6] = 0.02 * rng.standard_normal(3)
+    a[0:3] += jitter * rng.standard_normal(3)
+    return np.clip(a, -1, 1).astype(np.float32)
+
+
+def run_case(name, env_cfg, n_steps, seed, policy="random", tweak=None, global_step=0, reseed_each_reset=False,
+             state_every=1):
+    from environment import InterceptEnvironment
+
+    env = InterceptEnvironment(copy.deepcopy(env_cfg))
+    if global_step:
+        env.set_training_step_count(global_step)
+    arng = _orig_default_rng(seed + 77)
+
+    def do_reset(s):
+        TAPE.clear()
+        TAPE.mode = "reset"
+        TAPE._uniform_log = []
+        obs, info = env.reset(seed=s)
+        # assign the global-stream uniform draws to slots
+        calls = TAPE._uniform_log
+        spherical = env.missile_spawn_range.get("position_mode", "box") == "spherical"
+        slots = TAPE.reset
+        idx = 0
+        if spherical:
+            for j in range(3):
+                slots[j] = calls[idx][1][0]
+                idx += 1
+        else:
+            slots[0:3] = calls[idx][1]
+            idx += 1
+        slots[3] = calls[idx][1][0]
+        idx += 1
+        slots[4:7] = calls[idx][1]
+        idx += 1
+        last = calls[idx][1]
+        if len(last) == 3:
+            slots[7:10] = last
+        else:
+            slots[7] = last[0]
+        assert idx == len(calls) - 1
+        return obs.copy(), slots.copy()
+
+    obs0, reset_noise0 = do_reset(seed)
+    if tweak is not None:
+        tweak(env)
+    init_state = capture_state(env)
+    rec = dict(action=[], step_noise=[], obs=[], reward=[], terminated=[], truncated=[], distance=[],
+               intercepted=[], hit_target=[], info_min_distance=[], fuel_used=[], state=[],
+               did_reset=[], reset_noise=[], reset_obs=[], reset_state=[], radius=[], st_index=[])
+    for t in range(n_steps):
+        if policy == "random":
+            a = arng.uniform(-1, 1, 6).astype(np.float32)
+        elif policy == "pursuit":
+            a = pursuit_action(env, arng)
+        elif policy == "coast":
+            a = np.zeros(6, np.float32)
+            a[3:6] = arng.uniform(-1, 1, 3)
+        elif callable(policy):
+            a = policy(env, arng, t)
+        else:
+            raise ValueError(policy)
+        TAPE.clear()
+        TAPE.mode = "step"
+        obs, r, term, trunc, info = env.step(a)
+        rec["action"].append(a)
+        rec["step_noise"].append(TAPE.step.copy())
+        rec["obs"].append(obs.copy())
+        rec["reward"].append(np.float64(r))
+        rec["terminated"].append(bool(term))
+        rec["truncated"].append(bool(trunc))
+        rec["distance"].append(np.float64(info["distance"]))
+        rec["intercepted"].append(bool(info["intercepted"]))
+        rec["hit_target"].append(bool(info["missile_hit_target"]))
+        rec["info_min_distance"].append(np.float64(info["min_distance"]))
+        rec["fuel_used"].append(np.float64(info["fuel_used"]))
+        rec["radius"].append(np.float64(env.get_current_intercept_radius()))
+        if t % state_every == 0 or term or trunc or t == n_steps - 1:
+            # full post-step state (long cases keep every `state_every`-th one to stay small)
+            rec["state"].append(capture_state(env))
+            rec["st_index"].append(t)
+        if term or trunc:
+            ro, rn = do_reset(seed + 1000 + t if reseed_each_reset else None)
+            rec["did_reset"].append(True)
+            rec["reset_noise"].append(rn)
+            rec["reset_obs"].append(ro)
+            rec["reset_state"].append(capture_state(env))
+        else:
+            rec["did_reset"].append(False)
+    out = {"config_json": np.array(json.dumps(env_cfg)), "numpy_version": np.array(np.__version__),
+           "seed": np.int64(seed), "global_step": np.int64(global_step),
+           "reset_noise0": reset_noise0, "reset_obs0": obs0.astype(np.float32)}
+    for k, v in init_state.items():
+        out["init_" + k] = v
+    for k in ("action", "step_noise", "obs", "reward", "terminated", "truncated", "distance", "intercepted",
+              "hit_target", "info_min_distance", "fuel_used", "did_reset", "radius", "st_index"):
+        out[k] = np.array(rec[k])
+    for k, v in stack_states(rec["state"]).items():
+        out["st_" + k] = v
+    if rec["reset_state"]:
+        out["reset_noise"] = np.array(rec["reset_noise"])
+        out["reset_obs"] = np.array(rec["reset_obs"], np.float32)
+        for k, v in stack_states(rec["reset_state"]).items():
+            out["rst_" + k] = v
+    # shrink: float32 where the reference value is float32 anyway
+    for k in list(out.keys()):
+        v = out[k]
+        if isinstance(v, np.ndarray) and v.dtype == np.float64 and k.split("_", 1)[-1] in (
+                "int_pos", "int_vel", "int_quat", "mis_pos", "mis_vel", "wind", "thrust_actual", "kf_P"):
+            if np.array_equal(v.astype(np.float32).astype(np.float64), v, equal_nan=True):
+                out[k] = v.astype(np.float32)  # (simple-wind `wind` is float64 in the reference: kept as is)
+    n_ep = int(np.sum(out["did_reset"]))
+    print(f"{name:34s} steps={n_steps:5d} episodes_ended={n_ep:3d} intercepts={int(np.sum(out['intercepted'])):3d} "
+          f"reward_sum={float(np.sum(out['reward'])):12.2f}")
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
+# ---- forced edge cases: tweak the reference env's state right after reset ------------
+def tw_fuel_low(env):
+    env.interceptor_state["fuel"] = np.float32(0.05)
+
+
+def tw_missile_low_near(env):
+    env.missile_state["position"][:] = np.array([120.0, 90.0, 6.0], np.float32)
+    env.missile_state["velocity"][:] = np.array([-40.0, -30.0, -60.0], np.float32)
+
+
+def tw_missile_low_far(env):
+    env.missile_state["position"][:] = np.array([900.0, 800.0, 5.0], np.float32)
+    env.missile_state["velocity"][:] = np.array([-40.0, -30.0, -60.0], np.float32)
+
+
+def tw_interceptor_dive(env):
+    env.interceptor_state["position"][:] = np.array([10.0, 20.0, 3.0], np.float32)
+    env.interceptor_state["velocity"][:] = np.array([30.0, 10.0, -40.0], np.float32)
+
+
+def tw_close(env):
+    env.interceptor_state["position"][:] = env.missile_state["position"] - np.array([150.0, 120.0, 100.0], np.float32)
+    env.interceptor_state["velocity"][:] = np.array([200.0, 160.0, 120.0], np.float32)
+    d = np.linalg.norm(env.missile_state["position"] - env.interceptor_state["position"])
+    env._prev_distance = np.float32(d)
+    env._last_distance = env._prev_distance
+    env._episode_min_distance = env._prev_distance
+
+
+def tw_fast(env):
+    # interceptor/missile speeds spanning Mach 0.8 / 1.2
+    env.interceptor_state["velocity"][:] = np.array([150.0, 150.0, 160.0], np.float32)
+    env.missile_state["velocity"] *= np.float32(2.2)
+
+
+def tw_look_away(env):
+    # flip the radar away from the target: onboard loses the beam, ground radar may remain
+    env.interceptor_state["orientation"][:] = np.array([0.0, 1.0, 0.0, 0.0], np.float32)
+
+
+def tw_late(env):
+    # force the step>1000 smart-early-termination bookkeeping without 1000 recorded steps
+    env.steps = 1000
+    env._distance_worsening_count = 497
+    env.missile_state["position"] += np.array([1500.0, 1500.0, 900.0], np.float32)
+    env.missile_state["velocity"][:] = np.array([60.0, 60.0, 5.0], np.float32)
+    d = np.linalg.norm(env.missile_state["position"] - env.interceptor_state["position"])
+    env._prev_distance = np.float32(d)
+    env._last_distance = env._prev_distance
+    env._episode_min_distance = env._prev_distance
+
+
+def tw_blind(env):
+    # missile below ground-radar horizon and outside onboard range -> KF never initialised
+    env.missile_state["position"][:] = np.array([5200.0, 5100.0, 180.0], np.float32)
+    env.missile_state["velocity"][:] = np.array([-150.0, -150.0, -2.0], np.float32)
+    d = np.linalg.norm(env.missile_state["position"] - env.interceptor_state["position"])
+    env._prev_distance = np.float32(d)
+    env._last_distance = env._prev_distance
+    env._episode_min_distance = env._prev_distance
+
+
+def spin_then_random(env, rng, t):
+    a = rng.uniform(-1, 1, 6).astype(np.float32)
+    if (t // 40) % 2 == 0:
+        a[3:6] = np.array([1.0, -1.0, 0.7], np.float32)  # tumble: beam sweeps on/off the target
+    return a
+
+
+def main():
+    _install_gym_shim()
+    sys.path.insert(0, REF)
+    np.random.default_rng = _rec_default_rng
+    np.random.uniform = _rec_uniform
+    np.random.randn = _rec_randn
+    _selfcheck_wrappers()
+    for f in os.listdir(OUT):
+        if f.endswith(".npz"):
+            os.remove(os.path.join(OUT, f))
+
+    S = scenario_config
+    # --- scenario x physics, random actions -------------------------------------------
+    run_case("easy_config_random", S("easy", "config"), 300, 1000)
+    run_case("medium_base_random", S("medium", "base"), 400, 1001)
+    run_case("medium_v2_random", S("medium", "v2"), 400, 1002)
+    run_case("hard_base_random", S("hard", "base"), 250, 1003)
+    run_case("hard_v2_random", S("hard", "v2"), 250, 1004)
+    run_case("medium_flat_defaults", S("medium", "flat"), 250, 1005)
+    # short episodes -> many auto-resets (truncation), incl. domain randomisation
+    run_case("medium_base_short_eps", S("medium", "base", {"max_steps": 60}), 400, 1010)
+    run_case("medium_v2dr_short_eps", S("medium", "v2dr", {"max_steps": 50}), 420, 1011)
+    run_case("medium_v2dr_seeded_resets", S("medium", "v2dr", {"max_steps": 40}), 200, 1012, reseed_each_reset=True)
+    # --- pursuit controller: real intercepts, terminal rewards ------------------------
+    run_case("easy_config_pursuit", S("easy", "config"), 1500, 1020, policy="pursuit", state_every=25)
+    run_case("medium_base_pursuit", S("medium", "base"), 2000, 1021, policy="pursuit", state_every=25)
+    run_case("medium_v2_pursuit", S("medium", "v2"), 2000, 1022, policy="pursuit", state_every=25)
+    run_case("medium_base_pursuit_late_curric", S("medium", "base"), 2000, 1023, policy="pursuit",
+             global_step=1500000, state_every=25)
+    # --- observation modes -------------------------------------------------------------
+    run_case("medium_v2_body_random", S("medium", "v2", {"observation_mode": "body_frame"}), 250, 1030,
+             policy=spin_then_random)
+    run_case("medium_base_rotinv_random", S("medium", "base", {"rotation_invariant": True}), 200, 1031)
+    run_case("medium_v2_los_random", S("medium", "v2", {"observation_mode": "los_frame"}), 250, 1032,
+             policy=spin_then_random)
+    ev = load_yaml("configs/eval_360_los.yaml")
+    ec = copy.deepcopy(ev["environment"])
+    ec["curriculum"] = copy.deepcopy(ev["curriculum"])
+    ec["physics_enhancements"] = copy.deepcopy(ev["physics_enhancements"])
+    run_case("eval360_los_fuze_pursuit", ec, 1200, 1033, policy="pursuit", state_every=10)
+    ec2 = copy.deepcopy(ec)
+    ec2["proximity_fuze_enabled"] = False
+    ec2["curriculum"]["precision_mode"] = True
+    run_case("eval360_los_precision_pursuit", ec2, 1200, 1034, policy="pursuit", state_every=10)
+    # --- reward / termination modes ----------------------------------------------------
+    run_case("medium_base_precision_pursuit", S("medium", "base", {"curriculum.precision_mode": True}), 2000, 1040,
+             policy="pursuit", state_every=25)
+    run_case("medium_v2_fuze_pursuit", S("medium", "v2", {"proximity_fuze_enabled": True,
+                                                         "proximity_kill_radius": 30.0}), 2000, 1041,
+             policy="pursuit", state_every=25)
+    run_case("medium_base_nocurric", S("medium", "base", {"curriculum.enabled": False}), 150, 1042)
+    # --- forced edge cases ---------------------------------------------------------------
+    run_case("edge_fuel_out", S("medium", "v2"), 60, 1050, tweak=tw_fuel_low)
+    run_case("edge_fuel_out_base", S("medium", "base"), 60, 1051, tweak=tw_fuel_low)
+    run_case("edge_ground_hit_near", S("medium", "base"), 40, 1052, tweak=tw_missile_low_near)
+    run_case("edge_ground_hit_far", S("medium", "v2"), 40, 1053, tweak=tw_missile_low_far)
+    run_case("edge_crash", S("medium", "base"), 40, 1054, tweak=tw_interceptor_dive)
+    run_case("edge_close_intercept", S("medium", "base"), 80, 1055, tweak=tw_close, policy="coast")
+    run_case("edge_close_precision", S("medium", "v2", {"curriculum.precision_mode": True}), 120, 1056,
+             tweak=tw_close, policy="coast")
+    run_case("edge_mach_sweep", S("hard", "v2"), 200, 1057, tweak=tw_fast, policy="pursuit")
+    run_case("edge_look_away", S("medium", "v2"), 120, 1058, tweak=tw_look_away, policy="coast")
+    run_case("edge_early_termination", S("medium", "base", {"max_steps": 4000}), 60, 1059, tweak=tw_late,
+             policy="coast")
+    run_case("edge_blind_kf_uninit", S("medium", "v2"), 80, 1060, tweak=tw_blind, policy="coast")
+    run_case("edge_radar_curriculum_mid", S("medium", "base"), 120, 1061, global_step=6500000,
+             policy=spin_then_random)
+    run_case("edge_no_ground_radar", S("medium", "base", {"ground_radar": {"enabled": False}}), 100, 1062)
+
+
+if __name__ == "__main__":
+    main()
