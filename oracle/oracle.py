@@ -1,0 +1,176 @@
+"""ctypes binding of the CPU oracle (oracle/hlx_oracle.c).
+
+TEST INFRASTRUCTURE.  Importable only from tests/, `__graft_entry__.smoke()` and bench.py's
+`cpu_baseline` leg; the product package `hlynr_intercept_amd` never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+STEP_SLOTS, RESET_SLOTS, RING_CAP = 20, 32, 11
+
+d, i32, f32 = C.c_double, C.c_int32, C.c_float
+
+
+class OrcConfig(C.Structure):
+    _fields_ = [
+        ("dt", d), ("max_range", d), ("max_velocity", d), ("max_steps", i32),
+        ("target_pos", d * 3), ("mis_spawn_spherical", i32),
+        ("mis_pos_lo", d * 3), ("mis_pos_hi", d * 3),
+        ("mis_radius", d * 2), ("mis_azimuth_deg", d * 2), ("mis_elevation_deg", d * 2), ("mis_speed", d * 2),
+        ("int_pos_lo", d * 3), ("int_pos_hi", d * 3), ("int_vel_lo", d * 3), ("int_vel_hi", d * 3),
+        ("int_vel_toward_missile", i32), ("int_speed", d * 2),
+        ("atmosphere", i32), ("mach_drag", i32), ("enhanced_wind", i32), ("thrust_lag", i32),
+        ("domain_randomization", i32), ("validation", i32), ("evasion", i32),
+        ("subsonic_mach", d), ("supersonic_mach", d), ("transonic_peak_multiplier", d), ("supersonic_multiplier", d),
+        ("base_wind", d * 3), ("wind_variability", d), ("boundary_layer_height", d), ("turbulence_intensity", d),
+        ("gust_scale", d), ("thrust_tau", d), ("dr_variations", d * 13),
+        ("precision_mode", i32), ("proximity_fuze", i32), ("proximity_kill_radius", d),
+        ("radar_quality", d), ("radar_range", d), ("onboard_delay", i32), ("ground_enabled", i32),
+        ("ground_pos", d * 3), ("ground_max_range", d), ("ground_min_elev", d), ("ground_max_elev", d),
+        ("ground_range_accuracy", d), ("ground_velocity_accuracy", d), ("ground_base_quality", d),
+        ("max_datalink_range", d), ("datalink_packet_loss", d), ("ground_delay", i32), ("weather_factor", d),
+        ("obs_mode", i32),
+        ("intercept_radius", d), ("beam_width_deg", d), ("onboard_reliability", d), ("ground_reliability", d),
+    ]
+
+
+class OrcState(C.Structure):
+    _fields_ = [
+        ("int_pos", f32 * 3), ("int_vel", f32 * 3), ("int_quat", f32 * 4), ("fuel", f32),
+        ("thrust_actual", f32 * 3), ("mis_pos", f32 * 3), ("mis_vel", f32 * 3),
+        ("wind", d * 3), ("wind_is64", i32), ("steps", i32),
+        ("prev_distance", f32), ("min_distance", f32), ("last_distance", f32),
+        ("worsening", i32), ("crossed", i32),
+        ("kf_init", i32), ("kf_x_is64", i32), ("kf_x", d * 6), ("kf_P", f32 * 36),
+        ("on_delay", i32), ("on_count", i32), ("on_len", i32),
+        ("on_ring", (d * 3) * RING_CAP), ("on_det", i32 * RING_CAP),
+        ("g_count", i32), ("g_len", i32), ("g_ring", (d * 7) * RING_CAP), ("g_pos_is64", i32 * RING_CAP),
+        ("T0", d), ("base_cd", d), ("transonic_peak", d), ("total_fuel_used", d),
+        ("structure_violations", i32),
+    ]
+
+
+class OrcOut(C.Structure):
+    _fields_ = [
+        ("obs", f32 * 26), ("reward", d),
+        ("terminated", i32), ("truncated", i32), ("intercepted", i32), ("hit_target", i32),
+        ("fuze_triggered", i32), ("clamped", i32), ("distance", f32), ("min_distance", f32),
+    ]
+
+
+OUT_DTYPE = np.dtype([("obs", np.float32, 26), ("reward", np.float64), ("terminated", np.int32),
+                      ("truncated", np.int32), ("intercepted", np.int32), ("hit_target", np.int32),
+                      ("fuze_triggered", np.int32), ("clamped", np.int32), ("distance", np.float32),
+                      ("min_distance", np.float32)], align=True)
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/liboracle.so with the committed Makefile (gcc, -ffp-contract=off)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "hlx_oracle.c")
+    hdr = os.path.join(_HERE, "hlx_oracle.h")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        assert L.orc_sizeof_state() == C.sizeof(OrcState), (L.orc_sizeof_state(), C.sizeof(OrcState))
+        assert L.orc_sizeof_config() == C.sizeof(OrcConfig), (L.orc_sizeof_config(), C.sizeof(OrcConfig))
+        assert L.orc_sizeof_out() == C.sizeof(OrcOut) == OUT_DTYPE.itemsize
+        L.orc_init.argtypes = [C.POINTER(OrcConfig), C.c_void_p, i32]
+        L.orc_reset.argtypes = [C.POINTER(OrcConfig), C.POINTER(OrcState), C.POINTER(d), C.POINTER(f32)]
+        L.orc_step.argtypes = [C.POINTER(OrcConfig), C.POINTER(OrcState), C.POINTER(f32), C.POINTER(d),
+                               C.POINTER(OrcOut)]
+        L.orc_reset_batch.argtypes = [C.POINTER(OrcConfig), C.c_void_p, i32, C.c_void_p, C.c_void_p]
+        L.orc_step_batch.argtypes = [C.POINTER(OrcConfig), C.c_void_p, i32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, i32]
+        _lib = L
+    return _lib
+
+
+def make_config(rc, global_step=None, radar_step="same") -> OrcConfig:
+    """ResolvedConfig (hlynr_intercept_amd.config) + curriculum position -> orc_config.
+
+    `global_step=None` means `set_training_step_count` was never called (constructor state)."""
+    c = OrcConfig()
+    for name, _ in OrcConfig._fields_:
+        if name in ("intercept_radius", "beam_width_deg", "onboard_reliability", "ground_reliability"):
+            continue
+        v = getattr(rc, name)
+        if isinstance(v, (list, tuple)):
+            arr = getattr(c, name)
+            for k, x in enumerate(v):
+                arr[k] = float(x)
+        elif isinstance(v, bool):
+            setattr(c, name, int(v))
+        else:
+            setattr(c, name, v)
+    set_curriculum(c, rc, global_step)
+    return c
+
+
+def set_curriculum(c: OrcConfig, rc, global_step):
+    c.intercept_radius = rc.intercept_radius(0 if global_step is None else global_step)
+    sched = rc.radar_schedule(global_step)
+    c.beam_width_deg = sched["beam_width"]
+    c.onboard_reliability = sched["onboard_reliability"]
+    c.ground_reliability = sched["ground_reliability"]
+
+
+class OracleVec:
+    """N independent oracle envs with VecEnv auto-reset semantics; noise is an explicit input."""
+
+    def __init__(self, rc, n, global_step=None):
+        self.rc, self.n = rc, int(n)
+        self.cfg = make_config(rc, global_step)
+        self.L = lib()
+        self.state = (OrcState * self.n)()
+        self.L.orc_init(C.byref(self.cfg), C.addressof(self.state), self.n)
+        self.out = np.zeros(self.n, OUT_DTYPE)
+        self.terminal_obs = np.zeros((self.n, 26), np.float32)
+
+    def set_global_step(self, global_step):
+        set_curriculum(self.cfg, self.rc, global_step)
+
+    def reset(self, noise):
+        noise = np.ascontiguousarray(noise, np.float64)
+        assert noise.shape == (self.n, RESET_SLOTS)
+        obs = np.zeros((self.n, 26), np.float32)
+        self.L.orc_reset_batch(C.byref(self.cfg), C.addressof(self.state), self.n, noise.ctypes.data, obs.ctypes.data)
+        return obs
+
+    def step(self, actions, step_noise, reset_noise=None, auto_reset=True):
+        actions = np.ascontiguousarray(actions, np.float32)
+        step_noise = np.ascontiguousarray(step_noise, np.float64)
+        assert actions.shape == (self.n, 6) and step_noise.shape == (self.n, STEP_SLOTS)
+        if reset_noise is None:
+            assert not auto_reset
+            rn = None
+        else:
+            reset_noise = np.ascontiguousarray(reset_noise, np.float64)
+            assert reset_noise.shape == (self.n, RESET_SLOTS)
+            rn = reset_noise.ctypes.data
+        self.L.orc_step_batch(C.byref(self.cfg), C.addressof(self.state), self.n, actions.ctypes.data,
+                              step_noise.ctypes.data, rn, self.out.ctypes.data, self.terminal_obs.ctypes.data,
+                              int(auto_reset))
+        return self.out
+
+    # ---- state access (numpy views of selected fields) -----------------------------------------
+    def field(self, name):
+        """Copy of one state field for all envs as a numpy array."""
+        first = getattr(self.state[0], name)
+        if hasattr(first, "__len__"):
+            return np.array([np.ctypeslib.as_array(getattr(s, name)).copy() for s in self.state])
+        return np.array([getattr(s, name) for s in self.state])

@@ -1,0 +1,166 @@
+"""Helpers shared by the golden-vector tests (fixture loading, oracle replay)."""
+from __future__ import annotations
+
+import ctypes as C
+import glob
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+
+
+def fixture_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+
+
+def load_fixture(name):
+    d = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    fx = {k: d[k] for k in d.files}
+    fx["config"] = json.loads(str(fx["config_json"]))
+    gs = int(fx["global_step"])
+    fx["global_step_or_none"] = gs if gs != 0 else None   # generator only calls set_training_step_count if != 0
+    return fx
+
+
+# fields the forced-edge-case tweaks may overwrite after the first reset (make_golden.py tw_*)
+_INJECT = ["int_pos", "int_vel", "int_quat", "mis_pos", "mis_vel"]
+
+
+def inject_initial_state(st, fx):
+    """Overwrite the oracle env's kinematic state with the fixture's post-tweak state."""
+    for name in _INJECT:
+        arr = getattr(st, name)
+        for k, x in enumerate(fx["init_" + name]):
+            arr[k] = float(x)
+    st.fuel = float(fx["init_fuel"])
+    st.steps = int(fx["init_steps"])
+    st.prev_distance = float(fx["init_prev_distance"])
+    st.min_distance = float(fx["init_min_distance"])
+    st.last_distance = float(fx["init_last_distance"])
+    st.worsening = int(fx["init_worsening"])
+    st.crossed = int(fx["init_crossed"])
+
+
+def state_errors(st, ref, idx=None):
+    """Max abs / scaled errors of an oracle state vs a recorded reference state (dict of arrays)."""
+
+    def g(k):
+        v = ref[k]
+        return v if idx is None else v[idx]
+
+    errs = {}
+
+    def rel(a, b, scale):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return float(np.max(np.abs(a - b) / np.maximum(scale, np.abs(b)))) if a.size else 0.0
+
+    errs["int_pos"] = rel(list(st.int_pos), g("int_pos"), 1.0)
+    errs["int_vel"] = rel(list(st.int_vel), g("int_vel"), 1.0)
+    errs["int_quat"] = rel(list(st.int_quat), g("int_quat"), 1.0)
+    errs["mis_pos"] = rel(list(st.mis_pos), g("mis_pos"), 1.0)
+    errs["mis_vel"] = rel(list(st.mis_vel), g("mis_vel"), 1.0)
+    errs["wind"] = rel(list(st.wind), g("wind"), 1.0)
+    errs["thrust_actual"] = rel(list(st.thrust_actual), g("thrust_actual"), 1.0)
+    errs["fuel"] = rel(st.fuel, g("fuel"), 1.0)
+    errs["prev_distance"] = rel(st.prev_distance, g("prev_distance"), 1.0)
+    errs["min_distance"] = rel(st.min_distance, g("min_distance"), 1.0)
+    errs["last_distance"] = rel(st.last_distance, g("last_distance"), 1.0)
+    errs["kf_x"] = rel(list(st.kf_x), g("kf_x"), 1.0)
+    errs["kf_P"] = rel(np.array(list(st.kf_P)).reshape(6, 6), g("kf_P"), 1e-3)
+    errs["T0"] = rel(st.T0, g("T0"), 1.0)
+    errs["base_cd"] = rel(st.base_cd, g("base_cd"), 1.0)
+    errs["transonic_peak"] = rel(st.transonic_peak, g("transonic_peak"), 1.0)
+    ints = dict(steps=st.steps, worsening=st.worsening, crossed=st.crossed, kf_init=st.kf_init,
+                kf_x_is64=st.kf_x_is64, on_count=st.on_count, g_count=st.g_count)
+    for k, v in ints.items():
+        if int(v) != int(g(k)):
+            errs["INT_" + k] = (int(v), int(g(k)))
+    if int(g("on_delay")) > 0 and st.on_delay != int(g("on_delay")):
+        errs["INT_on_delay"] = (st.on_delay, int(g("on_delay")))
+    # delay rings (logical order)
+    on_ring = g("on_ring")
+    n_on = int(np.sum(~np.isnan(on_ring[:, 0]))) if on_ring.size else 0
+    if n_on != st.on_len:
+        errs["INT_on_len"] = (st.on_len, n_on)
+    elif n_on:
+        mine = np.array([list(st.on_ring[k]) for k in range(n_on)])
+        errs["on_ring"] = rel(mine, on_ring[:n_on], 1.0)
+        det = np.array([st.on_det[k] for k in range(n_on)])
+        if not np.array_equal(det, g("on_det")[:n_on]):
+            errs["INT_on_det"] = (det.tolist(), g("on_det")[:n_on].tolist())
+    g_ring = g("g_ring")
+    n_g = int(np.sum(~np.isnan(g_ring[:, 0]))) if g_ring.size else 0
+    if n_g != st.g_len:
+        errs["INT_g_len"] = (st.g_len, n_g)
+    elif n_g:
+        mine = np.array([list(st.g_ring[k]) for k in range(n_g)])
+        errs["g_ring"] = rel(mine, g_ring[:n_g], 1.0)
+    return errs
+
+
+def replay_oracle(fx, collect=None):
+    """Free-running replay of one fixture through the oracle (state is never re-synchronised).
+
+    Returns dict of max errors + lists of flag mismatches."""
+    import oracle.oracle as orc
+    from hlynr_intercept_amd.config import resolve_config
+
+    rc = resolve_config(fx["config"])
+    cfg = orc.make_config(rc, fx["global_step_or_none"])
+    L = orc.lib()
+    st = orc.OrcState()
+    L.orc_init(C.byref(cfg), C.addressof(st), 1)
+    obs = (C.c_float * 26)()
+    nz = np.ascontiguousarray(fx["reset_noise0"], np.float64)
+    L.orc_reset(C.byref(cfg), C.byref(st), nz.ctypes.data_as(C.POINTER(C.c_double)), obs)
+    res = dict(max_obs=0.0, max_reward=0.0, max_distance=0.0, flag_mismatch=[], state={}, int_mismatch=[],
+               reset_obs=0.0, n_steps=len(fx["action"]))
+    res["reset_obs"] = float(np.max(np.abs(np.array(obs[:]) - fx["reset_obs0"])))
+    inject_initial_state(st, fx)
+    init_ref = {k[5:]: v for k, v in fx.items() if k.startswith("init_")}
+    _merge(res, state_errors(st, init_ref), "init")
+    out = orc.OrcOut()
+    st_ref = {k[3:]: v for k, v in fx.items() if k.startswith("st_") and k != "st_index"}
+    rst_ref = {k[4:]: v for k, v in fx.items() if k.startswith("rst_")}
+    st_pos = {int(t): j for j, t in enumerate(fx["st_index"])}
+    n_reset = 0
+    for t in range(len(fx["action"])):
+        a = np.ascontiguousarray(fx["action"][t], np.float32)
+        z = np.ascontiguousarray(fx["step_noise"][t], np.float64)
+        L.orc_step(C.byref(cfg), C.byref(st), a.ctypes.data_as(C.POINTER(C.c_float)),
+                   z.ctypes.data_as(C.POINTER(C.c_double)), C.byref(out))
+        o = np.array(out.obs[:])
+        eo = float(np.max(np.abs(o - fx["obs"][t])))
+        res["max_obs"] = max(res["max_obs"], eo)
+        r_ref = float(fx["reward"][t])
+        res["max_reward"] = max(res["max_reward"], abs(out.reward - r_ref) / max(1.0, abs(r_ref)))
+        d_ref = float(fx["distance"][t])
+        res["max_distance"] = max(res["max_distance"], abs(out.distance - d_ref) / max(1.0, abs(d_ref)))
+        flags = (bool(out.terminated), bool(out.truncated), bool(out.intercepted), bool(out.hit_target))
+        ref_flags = (bool(fx["terminated"][t]), bool(fx["truncated"][t]), bool(fx["intercepted"][t]),
+                     bool(fx["hit_target"][t]))
+        if flags != ref_flags:
+            res["flag_mismatch"].append((t, flags, ref_flags))
+        if collect is not None:
+            collect(t, o, out)
+        if t in st_pos:
+            _merge(res, state_errors(st, st_ref, st_pos[t]), t)
+        if fx["did_reset"][t]:
+            nz = np.ascontiguousarray(fx["reset_noise"][n_reset], np.float64)
+            L.orc_reset(C.byref(cfg), C.byref(st), nz.ctypes.data_as(C.POINTER(C.c_double)), obs)
+            res["reset_obs"] = max(res["reset_obs"], float(np.max(np.abs(np.array(obs[:]) - fx["reset_obs"][n_reset]))))
+            _merge(res, state_errors(st, rst_ref, n_reset), f"reset{n_reset}")
+            n_reset += 1
+    res["structure_violations"] = st.structure_violations
+    return res
+
+
+def _merge(res, errs, where):
+    for k, v in errs.items():
+        if k.startswith("INT_"):
+            res["int_mismatch"].append((where, k, v))
+        else:
+            res["state"][k] = max(res["state"].get(k, 0.0), v)

@@ -1,0 +1,40 @@
+"""The CPU oracle (oracle/hlx_oracle.c) replayed against every golden fixture captured from the
+reference (tests/golden/make_golden.py).  This is what pins the oracle: free-running replay (the
+oracle's state is never re-synchronised to the reference's) over up to 2000 steps per case,
+including auto-resets, all observation modes, reward modes and forced edge cases.
+
+Tolerances: rewards, distances, flags and the integrated physics state come out bit-identical
+in practice; the Kalman-filter path differs by a few float32 ulps (BLAS sgemm accumulation order
+and SVML float32 transcendentals in the reference cannot be reproduced bit-for-bit), hence the
+small non-zero bounds below.  All are well inside the 1e-5 relative bar of BASELINE.json.
+"""
+import pytest
+
+from tests.golden_util import fixture_names, load_fixture, replay_oracle
+
+NAMES = fixture_names()
+
+
+def test_fixture_inventory():
+    assert len(NAMES) >= 30
+    for must in ("medium_base_random", "medium_v2_random", "medium_v2dr_short_eps", "eval360_los_fuze_pursuit",
+                 "medium_base_precision_pursuit", "edge_fuel_out", "edge_crash", "edge_early_termination",
+                 "edge_blind_kf_uninit", "edge_mach_sweep", "medium_v2_body_random", "medium_v2_los_random"):
+        assert must in NAMES
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_matches_reference(name):
+    fx = load_fixture(name)
+    assert str(fx["numpy_version"]).startswith("2."), "fixtures must come from a NEP-50 numpy"
+    r = replay_oracle(fx)
+    assert r["flag_mismatch"] == [], r["flag_mismatch"][:3]
+    assert r["int_mismatch"] == [], r["int_mismatch"][:3]
+    assert r["structure_violations"] == 0       # KF covariance keeps its 3 x (2x2) block structure
+    assert r["max_obs"] <= 1e-5, r["max_obs"]            # absolute, obs are O(1)
+    assert r["reset_obs"] <= 1e-6, r["reset_obs"]
+    assert r["max_reward"] <= 1e-6, r["max_reward"]      # relative to max(1,|r|)
+    assert r["max_distance"] <= 1e-6, r["max_distance"]
+    for k, v in r["state"].items():
+        tol = {"kf_x": 2e-4, "kf_P": 2e-5}.get(k, 1e-6)   # kf velocity states are weakly observed
+        assert v <= tol, (k, v)
