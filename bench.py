@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched intercept-environment step (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+One "step" = one `VecEnv.step` of the hot path over this rank's 65 536 environments (medium
+scenario, base physics, fp32; BASELINE.json configs[1]): ONE launch of the fused HIP kernel,
+auto-resets included.  Actions come from a pre-generated tape already resident in HBM; launches
+are issued back to back from C (`hlx_rollout`), one per step, as a policy-free rollout would.
+Environments shard over ranks with no collective in the step (weak scaling: 65 536 envs per GPU).
+
+Prints ONE JSON line on rank 0.  `value` = env-steps/s of the whole job (all ranks, max-over-ranks
+time).  `roofline` = algorithmic bytes of one launch / mean kernel duration from HIP events recorded
+on the launch stream around every launch of a second, identical K-step pass.  `cpu_baseline` = the
+CPU oracle (scalar C port of the reference's step, oracle/) timed on this host, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 65536
+BYTES_PER_ENV_STEP = {"base": 508, "v2dr": 604}     # SURVEY.md 8(d) algorithmic bytes per env-step
+HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(rc, budget_s=12.0):
+    """Scalar C port of the reference step (oracle/), OpenMP over envs on this host's cores."""
+    import oracle.oracle as orc
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = 16384
+    ov = orc.OracleVec(rc, n)
+    rng = np.random.default_rng(0)
+    ov.reset(rng.random((n, orc.RESET_SLOTS)))
+    acts = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+    sn = rng.standard_normal((n, orc.STEP_SLOTS))
+    sn[:, [6, 11, 12, 19]] = rng.random((n, 4))
+    rn = rng.random((n, orc.RESET_SLOTS))
+    ov.step(acts, sn, rn)   # warm
+    t0, steps = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s:
+        ov.step(acts, sn, rn)
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} envs x {steps} steps, medium scenario base physics, oracle/hlx_oracle.c with OpenMP over envs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--physics", default="base", choices=["base", "v2dr"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the step is a HIP kernel; there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # RCCL; used only for barrier + max(time)
+
+    from hlynr_intercept_amd.config import resolve_config
+    from hlynr_intercept_amd.scenarios import scenario_config
+    from hlynr_intercept_amd.vec_env import HlynrVecEnv
+
+    n = args.envs_per_gpu
+    rc = resolve_config(scenario_config("medium", args.physics))
+    env = HlynrVecEnv(resolved=rc, num_envs=n, device=local_rank, seed=1000, env_id_offset=rank * n)
+    dev = env.device
+    K, W = args.steps, args.warmup
+    gen = torch.Generator(device=dev).manual_seed(rank)      # fixed-seed synthetic action tape, U(-1, 1)
+    tape_len = max(K, W, 1)
+    tape = torch.rand((tape_len, n, 6), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
+    out_slots = 8
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    env.reset_torch()
+    if W:
+        env.rollout_torch(tape[:W], out_slots)
+    sync_all()
+    t0 = time.perf_counter()
+    env.rollout_torch(tape[:K], out_slots)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # identical second pass with HIP events around every launch -> mean kernel duration
+    env.profile(True)
+    env.rollout_torch(tape[:K], out_slots)
+    torch.cuda.synchronize(dev)
+    kern_ms, launches = env.profile_read()
+    env.profile(False)
+    kern_us = 1e3 * kern_ms / max(1, launches)
+    bytes_per_launch = BYTES_PER_ENV_STEP[args.physics] * n
+    achieved = bytes_per_launch / (kern_us * 1e-6) / 1e9 if launches else 0.0
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(rc)
+
+    if rank == 0:
+        total_steps = float(n) * K * world
+        line = {
+            "metric": "env-steps/sec whole-node, medium scenario, 64k envs/GPU",
+            "value": total_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"medium scenario, {args.physics} physics, {n} envs/GPU, fp32 "
+                                   f"(BASELINE.json configs[{1 if args.physics == 'base' else 2}])",
+                       "envs_per_gpu": n, "kernel_variant": env.kernel_variant, "launches_per_step": 1,
+                       "sharding": f"{world} x {n} independent envs, no collective in the step"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "hlx_env_kernel<%s, step>" % env.kernel_variant,
+                         "kernel_us": kern_us, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "launches_timed": launches},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    env.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

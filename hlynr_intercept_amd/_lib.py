@@ -1,0 +1,170 @@
+"""ctypes binding of include/hlx.h (the C ABI of libhlx.so).
+
+There is no fallback: if the HIP library is missing or fails to load, importing callers get a
+RuntimeError.  Nothing in this package routes through the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+f32, i32, u32, i64, u64, f64, u8p = C.c_float, C.c_int32, C.c_uint32, C.c_int64, C.c_uint64, C.c_double, C.c_void_p
+
+OBS_DIM, ACT_DIM, STEP_SLOTS, RESET_SLOTS, RING_CAP, MAX_STEPS = 26, 6, 20, 32, 11, 8191
+
+# hlx_flags
+F_ATMOSPHERE, F_MACH_DRAG, F_ENH_WIND, F_THRUST_LAG, F_DOMAIN_RAND, F_VALIDATION, F_EVASION, F_PRECISION = (
+    1 << 0, 1 << 1, 1 << 2, 1 << 3, 1 << 4, 1 << 5, 1 << 6, 1 << 7)
+F_PROX_FUZE, F_GROUND, F_SPHERICAL, F_TOWARD_MISSILE, F_OBS_BODY, F_OBS_LOS, F_USE_CURRICULUM, F_RADAR_CURRICULUM = (
+    1 << 8, 1 << 9, 1 << 10, 1 << 11, 1 << 12, 1 << 13, 1 << 14, 1 << 15)
+
+
+class HlxConfig(C.Structure):
+    _fields_ = [
+        ("flags", u32), ("max_steps", i32), ("dt", f32), ("max_range", f32), ("max_velocity", f32),
+        ("target_pos", f32 * 3), ("mis_pos_lo", f32 * 3), ("mis_pos_hi", f32 * 3),
+        ("mis_radius", f32 * 2), ("mis_azimuth_deg", f32 * 2), ("mis_elevation_deg", f32 * 2), ("mis_speed", f32 * 2),
+        ("int_pos_lo", f32 * 3), ("int_pos_hi", f32 * 3), ("int_vel_lo", f32 * 3), ("int_vel_hi", f32 * 3),
+        ("int_speed", f32 * 2),
+        ("subsonic_mach", f32), ("supersonic_mach", f32), ("transonic_peak_multiplier", f32),
+        ("supersonic_multiplier", f32),
+        ("base_wind", f32 * 3), ("wind_variability", f32), ("boundary_layer_height", f32),
+        ("turbulence_intensity", f32), ("gust_scale", f32), ("thrust_tau", f32),
+        ("dr_variations", f32 * 13), ("proximity_kill_radius", f32),
+        ("radar_quality", f32), ("radar_range", f32), ("radar_beam_width", f32), ("onboard_delay", i32),
+        ("ground_pos", f32 * 3), ("ground_max_range", f32), ("ground_min_elev", f32), ("ground_max_elev", f32),
+        ("ground_range_accuracy", f32), ("ground_velocity_accuracy", f32), ("ground_base_quality", f32),
+        ("max_datalink_range", f32), ("datalink_packet_loss", f32), ("weather_factor", f32), ("ground_delay", i32),
+        ("initial_radius", f64), ("final_radius", f64), ("curriculum_steps", f64),
+        ("rc_beam", f64 * 4), ("rc_onboard", f64 * 4), ("rc_ground", f64 * 4), ("rc_noise", f64 * 4),
+    ]
+
+
+class HlxInfoSoa(C.Structure):
+    _fields_ = [("distance", C.c_void_p), ("min_distance", C.c_void_p), ("fuel", C.c_void_p), ("flags", C.c_void_p),
+                ("episode_return", C.c_void_p), ("episode_length", C.c_void_p)]
+
+
+class HlxEnvState(C.Structure):
+    _fields_ = [
+        ("int_pos", f32 * 3), ("int_vel", f32 * 3), ("int_quat", f32 * 4), ("fuel", f32),
+        ("thrust_actual", f32 * 3), ("mis_pos", f32 * 3), ("mis_vel", f32 * 3), ("wind", f32 * 3),
+        ("prev_distance", f32), ("min_distance", f32), ("last_distance", f32),
+        ("steps", i32), ("worsening", i32), ("crossed", i32), ("kf_init", i32),
+        ("kf_x", f32 * 6), ("kf_P", f32 * 4),
+        ("on_delay", i32), ("on_len", i32), ("on_ring", (f32 * 4) * RING_CAP),
+        ("g_len", i32), ("g_ring", (f32 * 8) * RING_CAP),
+        ("T0", f32), ("base_cd", f32), ("transonic_peak", f32), ("ep_return", f32),
+    ]
+
+
+# every symbol include/hlx.h declares: (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "hlx_create": (C.c_int, [C.POINTER(HlxConfig), i32, i32, u64, i64, C.POINTER(_P)]),
+    "hlx_destroy": (C.c_int, [_P]),
+    "hlx_reset": (C.c_int, [_P, _P, _P, _P]),
+    "hlx_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(HlxInfoSoa), _P]),
+    "hlx_rollout": (C.c_int, [_P, _P, i32, i32, _P, _P, _P, _P, _P]),
+    "hlx_set_global_step": (C.c_int, [_P, i64]),
+    "hlx_get_curriculum": (C.c_int, [_P, C.POINTER(f64 * 5)]),
+    "hlx_set_noise": (C.c_int, [_P, _P, _P]),
+    "hlx_fill_noise": (C.c_int, [_P, _P, _P, i32, _P]),
+    "hlx_get_state": (C.c_int, [_P, _P]),
+    "hlx_set_state": (C.c_int, [_P, _P]),
+    "hlx_profile": (C.c_int, [_P, i32]),
+    "hlx_profile_read": (C.c_int, [_P, C.POINTER(f64), C.POINTER(i64)]),
+    "hlx_num_envs": (i32, [_P]),
+    "hlx_vec_steps": (i64, [_P]),
+    "hlx_kernel_variant": (C.c_char_p, [_P]),
+    "hlx_sizeof_config": (i32, []),
+    "hlx_sizeof_env_state": (i32, []),
+    "hlx_last_error": (C.c_char_p, []),
+    "hlx_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+class HlxError(RuntimeError):
+    pass
+
+
+def load(build_if_missing: bool = True):
+    """Load libhlx.so (building it in-tree with hipcc if absent).  Fails loudly; never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if build_if_missing and _build.needs_build():
+        try:
+            _build.build()
+        except Exception as exc:  # pragma: no cover
+            if not os.path.exists(path):
+                raise RuntimeError(f"libhlx.so is missing and could not be built: {exc}") from exc
+    if not os.path.exists(path):
+        raise RuntimeError(f"HIP library not found at {path}: build it with `python -m hlynr_intercept_amd.build`")
+    try:
+        lib = C.CDLL(path)
+    except OSError as exc:
+        raise RuntimeError(f"cannot load {path} (is the ROCm runtime, libamdhip64, present?): {exc}") from exc
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)   # AttributeError = symbol missing = broken build
+        fn.restype, fn.argtypes = res, args
+    if lib.hlx_sizeof_config() != C.sizeof(HlxConfig):
+        raise RuntimeError(f"hlx_config layout mismatch: C {lib.hlx_sizeof_config()} vs ctypes {C.sizeof(HlxConfig)}")
+    if lib.hlx_sizeof_env_state() != C.sizeof(HlxEnvState):
+        raise RuntimeError("hlx_env_state layout mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise HlxError(f"hlx error {rc}: {load().hlx_last_error().decode()}")
+
+
+def make_hlx_config(rc) -> HlxConfig:
+    """ResolvedConfig -> hlx_config (float32 parameters, float64 curriculum schedules)."""
+    c = HlxConfig()
+    flags = 0
+    for cond, bit in ((rc.atmosphere, F_ATMOSPHERE), (rc.mach_drag, F_MACH_DRAG), (rc.enhanced_wind, F_ENH_WIND),
+                      (rc.thrust_lag, F_THRUST_LAG), (rc.domain_randomization, F_DOMAIN_RAND),
+                      (rc.validation, F_VALIDATION), (rc.evasion, F_EVASION), (rc.precision_mode, F_PRECISION),
+                      (rc.proximity_fuze, F_PROX_FUZE), (rc.ground_enabled, F_GROUND),
+                      (rc.mis_spawn_spherical, F_SPHERICAL), (rc.int_vel_toward_missile, F_TOWARD_MISSILE),
+                      (rc.obs_mode == 1, F_OBS_BODY), (rc.obs_mode == 2, F_OBS_LOS),
+                      (rc.use_curriculum, F_USE_CURRICULUM), (rc.radar_curriculum.active, F_RADAR_CURRICULUM)):
+        if cond:
+            flags |= bit
+    c.flags = flags
+    simple = ("max_steps", "dt", "max_range", "max_velocity", "subsonic_mach", "supersonic_mach",
+              "transonic_peak_multiplier", "supersonic_multiplier", "wind_variability", "boundary_layer_height",
+              "turbulence_intensity", "gust_scale", "thrust_tau", "proximity_kill_radius", "radar_quality",
+              "radar_range", "radar_beam_width", "onboard_delay", "ground_max_range", "ground_min_elev",
+              "ground_max_elev", "ground_range_accuracy", "ground_velocity_accuracy", "ground_base_quality",
+              "max_datalink_range", "datalink_packet_loss", "weather_factor", "ground_delay", "initial_radius",
+              "final_radius", "curriculum_steps")
+    for k in simple:
+        setattr(c, k, getattr(rc, k))
+    for k in ("target_pos", "mis_pos_lo", "mis_pos_hi", "mis_radius", "mis_azimuth_deg", "mis_elevation_deg",
+              "mis_speed", "int_pos_lo", "int_pos_hi", "int_vel_lo", "int_vel_hi", "int_speed", "base_wind",
+              "dr_variations", "ground_pos"):
+        arr = getattr(c, k)
+        for j, x in enumerate(getattr(rc, k)):
+            arr[j] = float(x)
+    cur = rc.radar_curriculum
+    for name, vals in (("rc_beam", (cur.initial_beam_width, cur.final_beam_width, cur.beam_width_transition_start,
+                                    cur.beam_width_transition_end)),
+                       ("rc_onboard", (cur.initial_detection_reliability, cur.final_detection_reliability,
+                                       cur.reliability_transition_start, cur.reliability_transition_end)),
+                       ("rc_ground", (cur.initial_ground_reliability, cur.final_ground_reliability,
+                                      cur.ground_reliability_transition_start, cur.ground_reliability_transition_end)),
+                       ("rc_noise", (cur.initial_noise_level, cur.final_noise_level, cur.noise_transition_start,
+                                     cur.noise_transition_end))):
+        arr = getattr(c, name)
+        for j, x in enumerate(vals):
+            arr[j] = float(x)
+    return c

@@ -1,0 +1,169 @@
+// hlx_device.h -- device-side building blocks of the fused intercept-environment step (gfx950).
+//
+// One lane = one environment.  Everything here is float32 and register resident; the only
+// LDS use is the [64][26] observation tile that turns per-lane rows into coalesced 16-byte
+// stores (see hlx_kernels.hip).  No MFMA: the path is per-environment physics, not a contraction.
+//
+// Citations are to the reference (RomanSlack/Hlynr_Intercept, rl_system/...), whose arithmetic
+// these functions restate; oracle/hlx_oracle.c is the CPU restatement they are tested against.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DEV __device__ __forceinline__
+
+namespace hlx {
+
+struct V3 {
+    float x, y, z;
+};
+DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+DEV V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+DEV V3 operator*(float s, V3 a) { return V3{a.x * s, a.y * s, a.z * s}; }
+DEV V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DEV float norm(V3 a) { return sqrtf(dot(a, a)); }
+DEV V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+DEV V3 clamp3(V3 a, float lo, float hi) { return V3{clampf(a.x, lo, hi), clampf(a.y, lo, hi), clampf(a.z, lo, hi)}; }
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based RNG: Philox4x32-10 keyed by the env-set seed; counter = (global env id, vec-step,
+// stream).  Results therefore do not depend on sharding or launch geometry.
+// ---------------------------------------------------------------------------------------------
+DEV uint4 philox4x32_10(uint4 c, uint2 k) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
+        uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+        c = uint4{hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0};
+        k.x += W0;
+        k.y += W1;
+    }
+    return c;
+}
+DEV float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }          // [0,1)
+DEV float u01_open(uint32_t x) { return (float)((x >> 8) + 1u) * 5.9604644775390625e-08f; } // (0,1]
+// Box-Muller on two 32-bit words; v_sin/v_cos take revolutions, so 2*pi*u needs no range reduction.
+DEV void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
+    float r = sqrtf(-2.0f * __logf(u01_open(a)));
+    float u = u01(b);
+    z0 = r * __builtin_amdgcn_cosf(u);
+    z1 = r * __builtin_amdgcn_sinf(u);
+}
+
+struct Rng {
+    uint2 key;
+    uint32_t id_lo, id_hi, t_lo, t_hi;
+    DEV uint4 raw(uint32_t stream) const { return philox4x32_10(uint4{id_lo, id_hi, t_lo, (t_hi << 8) | stream}, key); }
+    DEV void normals4(uint32_t stream, float& a, float& b, float& c, float& d) const {
+        uint4 x = raw(stream);
+        box_muller(x.x, x.y, a, b);
+        box_muller(x.z, x.w, c, d);
+    }
+};
+// stream ids (RS_GUST uses two consecutive streams: 5 and 6)
+enum : uint32_t {
+    RS_STEP_U = 0, RS_EVASION = 1, RS_WIND = 2, RS_GPOS = 3, RS_GVEL = 4, RS_GUST = 5,
+    RS_RESET_U0 = 8, RS_RESET_U1 = 9, RS_RESET_U2 = 10, RS_RESET_OBS_U = 11, RS_RESET_GPOS = 12, RS_RESET_GVEL = 13,
+    RS_DR0 = 14, RS_DR1 = 15, RS_DR2 = 16, RS_DR3 = 17
+};
+
+// physics_models.py:382-384 gust direction N(0,1)^3 and magnitude Exp(1)
+DEV void gust_draws(const Rng& rng, struct V3& g, float& e) {
+    uint4 x = rng.raw(RS_GUST), y = rng.raw(RS_GUST + 1);
+    float w_;
+    box_muller(x.x, x.y, g.x, g.y);
+    box_muller(x.z, x.w, g.z, w_);
+    e = -__logf(u01_open(y.x));
+}
+
+// ---------------------------------------------------------------------------------------------
+// physics_models.py:154-177  ISA atmosphere -> density, speed of sound
+// ---------------------------------------------------------------------------------------------
+DEV void atmosphere(float alt, float T0, float& rho, float& sos) {
+    constexpr float R = 287.05f, G = 9.80665f, L = 0.0065f;
+    constexpr float EXPO = (float)(9.80665 / (287.05 * 0.0065));
+    constexpr float GAMMA_R = (float)(1.4 * 287.05);
+    float T, P;
+    if (alt <= 11000.0f) {
+        T = T0 - L * alt;                         // :70-71
+        P = 101325.0f * powf(T / T0, EXPO);       // :95-100
+    } else if (alt <= 20000.0f) {                 // :72-74,102-108 (not reachable in shipped scenarios)
+        T = 216.65f;
+        P = 22632.0f * expf(-G * (alt - 11000.0f) / (R * 216.65f));
+    } else {                                      // :76-78,110-113
+        float ex = alt - 20000.0f;
+        T = 216.65f * expf(-ex / 10000.0f);
+        const float Pb = 5474.790039909648f;      // 22632 * exp(-g*9000/(R*216.65))  (:112)
+        P = Pb * expf(-ex / 6000.0f);
+    }
+    rho = P / (R * T);                            // :166
+    sos = sqrtf(GAMMA_R * T);                     // :167-169
+}
+
+struct DragParams {
+    float subsonic, supersonic, peak, super_mult, base_cd;
+};
+// physics_models.py:236-264 drag force / mass -> acceleration (area, extra scale folded in by caller)
+DEV V3 mach_drag_accel(V3 v, float rho, float sos, float area_scale, float inv_mass, const DragParams& p) {
+    float vm = norm(v);
+    if (vm < 1e-6f) return v3(0.f, 0.f, 0.f);
+    float mach = vm / sos;                        // :233-234
+    float cd;
+    if (mach < p.subsonic) cd = p.base_cd;        // :207-209
+    else if (mach < p.supersonic) {
+        float frac = (mach - p.subsonic) / (p.supersonic - p.subsonic);   // :213-214
+        cd = p.base_cd * (1.0f + (p.peak - 1.0f) * frac);                 // :215-216
+    } else cd = p.base_cd * p.super_mult;         // :220
+    float mag = 0.5f * rho * (vm * vm) * cd * area_scale;                 // :258
+    float k = -(mag / vm) * inv_mass;             // :262-264
+    return v * k;
+}
+// environment.py:920-921, 1099-1100
+DEV V3 simple_drag_accel(V3 v, float rho, float inv_mass) {
+    float k = (-0.5f * 0.3f) * rho * norm(v) * inv_mass;
+    return v * k;
+}
+// environment.py:927-930 / 1111-1113 nan_to_num(nan=0, +-inf=+-lim) applied when any component is non-finite
+DEV V3 nan_guard(V3 a, float lim) {
+    bool ok = isfinite(a.x) && isfinite(a.y) && isfinite(a.z);
+    if (ok) return a;
+    auto fix = [lim](float x) { return isnan(x) ? 0.0f : (isinf(x) ? (x > 0.f ? lim : -lim) : x); };
+    return V3{fix(a.x), fix(a.y), fix(a.z)};
+}
+
+// ---------------------------------------------------------------------------------------------
+// quaternion helpers  core.py:1103-1205 ([w, x, y, z])
+// ---------------------------------------------------------------------------------------------
+struct Quat {
+    float w, x, y, z;
+};
+DEV V3 forward_vec(Quat q) {   // core.py:1143-1152
+    V3 f = v3(2.f * (q.x * q.z + q.w * q.y), 2.f * (q.y * q.z - q.w * q.x), 1.f - 2.f * (q.x * q.x + q.y * q.y));
+    return f * (1.0f / (norm(f) + 1e-6f));
+}
+DEV V3 right_vec(Quat q) {     // core.py:1155-1164
+    V3 f = v3(1.f - 2.f * (q.y * q.y + q.z * q.z), 2.f * (q.x * q.y + q.w * q.z), 2.f * (q.x * q.z - q.w * q.y));
+    return f * (1.0f / (norm(f) + 1e-6f));
+}
+DEV V3 up_vec(Quat q) {        // core.py:1167-1176
+    V3 f = v3(2.f * (q.x * q.y - q.w * q.z), 1.f - 2.f * (q.x * q.x + q.z * q.z), 2.f * (q.y * q.z + q.w * q.x));
+    return f * (1.0f / (norm(f) + 1e-6f));
+}
+DEV Quat quat_mul(Quat a, Quat b) {  // environment.py:1322-1331
+    return Quat{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+                a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+// LOS orthonormal basis: environment.py:1006-1020 == core.py:824-834,939-945
+DEV void los_basis(V3 lu, V3& h, V3& v) {
+    V3 right = cross(lu, v3(0.f, 0.f, 1.f));
+    float n = norm(right);
+    h = (n > 1e-6f) ? right * (1.0f / n) : v3(1.f, 0.f, 0.f);
+    v = cross(lu, h);
+}
+
+}  // namespace hlx

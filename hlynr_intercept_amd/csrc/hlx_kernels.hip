@@ -1,0 +1,664 @@
+// hlx_kernels.hip -- the fused intercept-environment step for MI355X (gfx950 / CDNA4).
+//
+// One kernel launch = one `VecEnv.step`: safety clamp -> interceptor 6-DOF integrator -> missile
+// -> wind -> intercept/termination -> reward -> radar/ground-radar/datalink/fusion -> Kalman filter
+// -> 26-D observation, plus the auto-reset (spawn + first observation) of finished environments.
+// Reference order of operations: rl_system/environment.py:605-859.
+//
+// Mapping to the hardware
+//   * one lane per environment, 64-lane workgroups (= one wavefront): no workgroup barrier is ever
+//     needed between waves, and N/64 workgroups spread evenly over the 256 CUs / 8 XCDs.  The
+//     env -> workgroup mapping is the same every launch, so the slice of the arena a workgroup
+//     touches stays in the L2 of the XCD it is dispatched to (round-robin by workgroup id).
+//   * state arena = struct-of-arrays of float4 "groups": every state load/store is a 16-byte-per-
+//     lane, 1 KiB-per-wave fully coalesced access (9 groups base physics, 11 with physics v2).
+//   * delay rings are planes indexed by the GLOBAL vec-step clock, so ring traffic is coalesced
+//     too although every environment is at a different step of its own episode.
+//   * the 26-float observation row of each lane goes through a [64][26] LDS tile and leaves as
+//     16-byte coalesced stores of the row-major [N][26] array the policy consumes.
+//   * finished environments: wave ballot + popcount + one atomic per wave compacts their indices.
+//   * no MFMA: per-environment physics has no dense contraction (HBM/latency bound).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hlx.h"
+#include "hlx_device.h"
+#include "hlx_kargs.h"
+
+using namespace hlx;
+
+namespace {
+
+#define HAS(f) ((FL & (uint32_t)(f)) != 0u)
+
+template <uint32_t SPEC, int MODE /*0 = step, 1 = reset-only*/>
+__global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
+    __shared__ __attribute__((aligned(16))) float tile[64 * HLX_OBS_DIM];
+    const uint32_t FL = (SPEC & KF_DYNAMIC) ? a.c.flags : SPEC;
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x * 64 + lane;
+    const int n = a.n;
+    const bool live = i < n;
+    const unsigned long long t = a.t_add + (a.t_dev ? *a.t_dev : 0ull);
+    const KCfg& c = a.c;
+    float* row = tile + lane * HLX_OBS_DIM;
+    bool done = false;
+
+    if (live) {
+        const size_t N = (size_t)n;
+        float4* A = a.arena + i;
+        // ------------------------------------------------------------------ load state
+        float4 g_ipos = A[G_IPOS * N], g_ivel = A[G_IVEL * N], g_quat = A[G_QUAT * N], g_mpos = A[G_MPOS * N];
+        float4 g_mvel = A[G_MVEL * N], g_wind = A[G_WIND * N], g_kfp = A[G_KFP * N], g_kfv = A[G_KFV * N];
+        float4 g_misc = A[G_MISC * N];
+        float4 g_thr = make_float4(0.f, 0.f, 0.f, 0.f), g_dr = make_float4(0.3f, c.peak, 0.f, 0.f);
+        if (HAS(HLX_F_THRUST_LAG)) g_thr = A[G_THRUST * N];
+        if (HAS(HLX_F_DOMAIN_RAND)) g_dr = A[G_DR * N];
+
+        V3 ipos = v3(g_ipos.x, g_ipos.y, g_ipos.z), ivel = v3(g_ivel.x, g_ivel.y, g_ivel.z);
+        Quat q = Quat{g_quat.x, g_quat.y, g_quat.z, g_quat.w};
+        V3 mpos = v3(g_mpos.x, g_mpos.y, g_mpos.z), mvel = v3(g_mvel.x, g_mvel.y, g_mvel.z);
+        V3 wind = v3(g_wind.x, g_wind.y, g_wind.z);
+        float fuel = g_ipos.w, prev_distance = g_ivel.w, min_distance = g_mpos.w, last_distance = g_mvel.w;
+        uint32_t packed = __float_as_uint(g_wind.w);
+        int steps = (int)(packed & 0x1FFFu), worsening = (int)((packed >> 13) & 0x1FFFu);
+        bool crossed = (packed >> 26) & 1u, kf_init = (packed >> 27) & 1u;
+        int on_delay = (int)(packed >> 28);
+        V3 kxp = v3(g_kfp.x, g_kfp.y, g_kfp.z), kxv = v3(g_kfv.x, g_kfv.y, g_kfv.z);
+        float p_pp = g_kfp.w, p_pv = g_kfv.w, p_vp = g_misc.x, p_vv = g_misc.y, ep_return = g_misc.z, T0 = g_misc.w;
+        V3 thrust_act = v3(g_thr.x, g_thr.y, g_thr.z);
+        DragParams dp{c.subsonic, c.supersonic, g_dr.y, c.super_mult, g_dr.x};
+
+        const bool noise_buf = a.step_noise != nullptr;
+        const unsigned long long gid = (unsigned long long)(a.env_offset + i);
+        Rng rng{uint2{a.seed_lo, a.seed_hi}, (uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)t, (uint32_t)(t >> 32)};
+        const float* SN = a.step_noise + i;   // slot-major [slot][N]
+        const float* RN = a.reset_noise + i;
+
+        float reward = 0.f, distance = 0.f;
+        bool terminated = false, truncated = false, intercepted = false, hit_target = false, fuze = false,
+             clamped = false;
+
+        if (MODE == 0) {
+            // -------------------------------------------------------------- action (environment.py:605-625)
+            const float2* ap = reinterpret_cast<const float2*>(a.actions + (size_t)i * HLX_ACT_DIM);
+            float2 a01 = ap[0], a23 = ap[1], a45 = ap[2];
+            V3 at = v3(a01.x, a01.y, a23.x), aw = v3(a23.y, a45.x, a45.y);
+            const float los_a0 = at.x;
+            steps += 1;                                                             // :607
+            if (HAS(HLX_F_OBS_LOS)) {                                               // :618-620, :965-1063
+                V3 rel0 = mpos - ipos;
+                float rg = norm(rel0);
+                V3 lu = (rg > 1e-6f) ? rel0 * (1.0f / rg) : v3(1.f, 0.f, 0.f);
+                V3 h, v;
+                los_basis(lu, h, v);
+                at = lu * at.x + h * at.y + v * at.z;
+            }
+            if (fuel <= 0.f) { at = at * 0.f; clamped = true; }                      // core.py:1080-1083
+            float am = norm(at);
+            if (am > 50.f) { at = at * (50.f / am); clamped = true; }                // core.py:1086-1090
+            float gm = norm(aw);
+            if (gm > 5.f) { aw = aw * (5.f / gm); clamped = true; }                  // core.py:1094-1098
+
+            // -------------------------------------------------------------- interceptor (environment.py:861-956)
+            V3 thr = at * 10000.f, ang = aw * 20.f;                                 // :870-871
+            if (HAS(HLX_F_THRUST_LAG)) {                                            // :874-878
+                V3 err = thr - thrust_act;
+                thrust_act = thrust_act + (err * c.dt) * (1.0f / c.thrust_tau);
+                thr = thrust_act;
+            }
+            float fc = norm(thr) / 500.f * 0.1f * c.dt;                             // :883-884
+            fuel -= fc;
+            if (fuel <= 0.f) { fuel = 0.f; thr = v3(0.f, 0.f, 0.f); thrust_act = thr; } // :888-892
+            float rho = 1.225f, sos = 343.f;
+            if (HAS(HLX_F_ATMOSPHERE)) atmosphere(fmaxf(ipos.z, 0.f), T0, rho, sos); // :899-906
+            const V3 grav = v3(0.f, 0.f, -9.81f);
+            {
+                V3 va = ivel - wind;                                                // :910
+                V3 dacc;
+                if (HAS(HLX_F_MACH_DRAG) && norm(va) > 1e-6f) dacc = mach_drag_accel(va, rho, sos, 1.0f, 1.0f / 500.f, dp);
+                else dacc = simple_drag_accel(va, rho, 1.0f / 500.f);               // :912-921
+                V3 acc = thr * (1.0f / 500.f) + dacc + grav;                        // :896,:924
+                if (HAS(HLX_F_VALIDATION)) acc = nan_guard(acc, 50.f);
+                ivel = ivel + acc * c.dt;                                           // :933
+                ipos = ipos + ivel * c.dt;                                          // :934
+            }
+            {
+                float wn = norm(ang);                                               // :940-956
+                float angle = wn * c.dt;
+                if (angle > 1e-6f) {
+                    float sh, ch;
+                    sincosf(0.5f * angle, &sh, &ch);
+                    float k = sh / wn;
+                    Quat r = quat_mul(Quat{ch, ang.x * k, ang.y * k, ang.z * k}, q);
+                    float inv = 1.0f / sqrtf(r.w * r.w + r.x * r.x + r.y * r.y + r.z * r.z);
+                    q = Quat{r.w * inv, r.x * inv, r.y * inv, r.z * inv};
+                }
+            }
+            // -------------------------------------------------------------- missile (environment.py:1069-1117)
+            {
+                float mrho = 1.225f, msos = 343.f;
+                if (HAS(HLX_F_ATMOSPHERE)) atmosphere(fmaxf(mpos.z, 0.f), T0, mrho, msos);
+                V3 va = mvel - wind;
+                V3 dacc;
+                if (HAS(HLX_F_MACH_DRAG) && norm(va) > 1e-6f) dacc = mach_drag_accel(va, mrho, msos, 2.0f * 1.5f, 1.0f / 1000.f, dp);
+                else dacc = simple_drag_accel(va, mrho, 1.0f / 1000.f);
+                V3 acc = dacc + grav;
+                if (HAS(HLX_F_EVASION)) {                                           // :1103-1105
+                    V3 z;
+                    if (noise_buf) z = v3(SN[0 * N], SN[1 * N], SN[2 * N]);
+                    else { float w_; rng.normals4(RS_EVASION, z.x, z.y, z.z, w_); }
+                    acc = acc + z * 2.0f;
+                }
+                if (HAS(HLX_F_VALIDATION)) acc = nan_guard(acc, 20.f);
+                mvel = mvel + acc * c.dt;                                           // :1116
+                mpos = mpos + mvel * c.dt;                                          // :1117
+            }
+            // -------------------------------------------------------------- wind (environment.py:1119-1129)
+            if (HAS(HLX_F_ENH_WIND)) {                                              // physics_models.py:351-387
+                float walt = fmaxf(ipos.z, 0.f);
+                float prof, ti;
+                if (walt <= 10.f) { prof = 1.0f; ti = c.turb * 2.0f; }
+                else if (walt <= c.bl_height) {
+                    prof = powf(walt / 10.f, 0.143f);                               // :319-324
+                    ti = c.turb * (1.0f - (walt / c.bl_height) * 0.7f);             // :343-346
+                } else { prof = c.bl_prof; ti = c.turb * 0.3f; }
+                V3 w = v3(c.base_wind[0], c.base_wind[1], c.base_wind[2]) * prof;
+                V3 z; float gu;
+                if (noise_buf) { z = v3(SN[3 * N], SN[4 * N], SN[5 * N]); gu = SN[6 * N]; }
+                else {
+                    float w_; rng.normals4(RS_WIND, z.x, z.y, z.z, w_);
+                    gu = u01(rng.raw(RS_STEP_U).w);
+                }
+                if (ti > 0.f) w = w + z * (ti * norm(w) * c.turb_lp);               // :370-378
+                if (gu < 0.001f) {                                                  // :381-385
+                    V3 g; float e;
+                    if (noise_buf) { g = v3(SN[7 * N], SN[8 * N], SN[9 * N]); e = SN[10 * N]; }
+                    else {
+                        gust_draws(rng, g, e);
+                    }
+                    w = w + g * (c.gust_scale * e / (norm(g) + 1e-6f));
+                }
+                wind = w;
+            } else if (c.wind_var > 0.f) {                                          // :1127-1129
+                V3 z;
+                if (noise_buf) z = v3(SN[3 * N], SN[4 * N], SN[5 * N]);
+                else { float w_; rng.normals4(RS_WIND, z.x, z.y, z.z, w_); }
+                V3 bw = v3(c.base_wind[0], c.base_wind[1], c.base_wind[2]);
+                wind = wind * 0.95f + (bw + z * c.wind_var) * 0.05f;
+            }
+            // -------------------------------------------------------------- intercept / termination (:657-814)
+            V3 rel = mpos - ipos;
+            distance = norm(rel);
+            if (HAS(HLX_F_PROX_FUZE)) intercepted = distance < c.kill_radius;       // :700-703
+            else intercepted = distance < a.radius;
+            min_distance = (distance < min_distance) ? distance : min_distance;     // :706
+            if (intercepted) crossed = true;                                        // :709-710
+            if (HAS(HLX_F_PROX_FUZE) && min_distance < c.kill_radius) { fuze = true; intercepted = true; } // :715-717
+            const bool ground = mpos.z <= 0.f;
+            const float gdx = mpos.x - c.target[0], gdy = mpos.y - c.target[1];
+            const bool near_target = sqrtf(gdx * gdx + gdy * gdy) < 500.f;
+            if (HAS(HLX_F_PRECISION)) {                                             // :752-767
+                if (ground) { terminated = true; hit_target = near_target; }
+            } else {                                                                // :769-786
+                if (intercepted) terminated = true;
+                else if (ground) { terminated = true; hit_target = near_target; }
+            }
+            if (ipos.z < 0.f) terminated = true;                                    // :789-811
+            else if (fuel <= 0.f) terminated = true;
+            else if (steps > 1000) {
+                if (distance > last_distance) worsening = min(worsening + 1, 0x1FFF);
+                else worsening = max(0, worsening - 5);
+                last_distance = distance;
+                if (worsening > 500 && distance > 2500.f) terminated = true;
+            }
+            truncated = steps >= c.max_steps;                                       // :813-814
+            // -------------------------------------------------------------- reward (:1131-1320)
+            if (HAS(HLX_F_PRECISION)) {
+                if (terminated) {                                                   // :1155-1201
+                    float md = min_distance;
+                    if (crossed) {
+                        reward = 3000.f;
+                        if (md < a.radius) reward += (a.radius - md) / a.radius * 1000.f;
+                        reward += expf(-md / 25.f) * 500.f;
+                        reward += expf(-md / 10.f) * 1000.f;
+                        reward += expf(-md / 3.f) * 500.f;
+                        reward += (float)(c.max_steps - steps) * 0.3f;
+                    } else {
+                        reward = fmaxf(-md * 0.5f, -2000.f);
+                        if (hit_target) reward -= 1000.f;
+                        else if (ipos.z < 0.f) reward -= 500.f;
+                        else if (fuel <= 0.f) reward -= 300.f;
+                    }
+                } else {                                                            // :1203-1271
+                    float delta = prev_distance - distance;
+                    reward = clampf((delta / c.dt) / 100.f, -0.5f, 2.0f) * 0.5f;
+                    if (distance < 50.f) { reward += delta * 5.f; reward += expf(-distance / 10.f); }
+                    else if (distance < 150.f) reward += delta * 3.f;
+                    else if (distance < 500.f) reward += delta * 1.5f;
+                    else reward += delta * 0.8f;
+                    float isp = norm(ivel);
+                    if (isp > 1.0f && distance > 10.f) reward += dot(ivel * (1.0f / isp), rel * (1.0f / distance)) * 0.3f;
+                    if (HAS(HLX_F_OBS_LOS)) reward += los_a0 * 0.4f;
+                    reward -= 0.2f;
+                    prev_distance = distance;
+                }
+            } else if (intercepted) {                                               // :1274-1282
+                reward = 5000.f + (float)(c.max_steps - steps) * 0.5f;
+            } else if (terminated) {                                                // :1284-1296
+                reward = fmaxf(-distance * 0.5f, -2000.f);
+                if (hit_target) reward -= 1000.f;
+                else if (ipos.z < 0.f) reward -= 500.f;
+                else if (fuel <= 0.f) reward -= 300.f;
+            } else {                                                                // :1298-1320
+                float delta = prev_distance - distance;
+                reward = clampf((delta / c.dt) / 100.f, -0.5f, 2.0f) * 0.3f;
+                reward += delta * ((distance < 200.f) ? 2.0f : (distance < 500.f) ? 1.0f : 0.5f);
+                reward -= 0.5f;
+                prev_distance = distance;
+            }
+            done = terminated || truncated;
+            ep_return += reward;
+        } else {
+            // reset-only launch: `done` marks the envs to reset
+            done = a.reset_mask ? (a.reset_mask[i] != 0) : true;
+        }
+
+        // ---------------------------------------------------------------------- observation (+ auto-reset)
+        // pass 0: observation of the stepped state.  pass 1 (only if some lane of the wave finished):
+        // finished lanes respawn (environment.py:353-603) and build their first observation.
+        const int g_cap = c.g_delay + 1, o_cap = c.o_cap;
+        float4 on_sample = make_float4(0.f, 0.f, 0.f, 0.f), g_s0 = on_sample, g_s1 = on_sample;
+        uint32_t det_bits = 0;
+#pragma unroll 1
+        for (int pass = (MODE == 0 ? 0 : 1); pass < 2; ++pass) {
+            const bool act = (pass == 0) || done;
+            if (pass == 1) {
+                if (__ballot(done) == 0ull) break;
+                if (done) {
+                    if (MODE == 0) {
+                        if (a.terminal_obs) {
+                            float* to = a.terminal_obs + (size_t)i * HLX_OBS_DIM;
+#pragma unroll
+                            for (int k = 0; k < HLX_OBS_DIM; ++k) to[k] = row[k];
+                        }
+                        if (a.info.episode_return) a.info.episode_return[i] = ep_return;
+                        if (a.info.episode_length) a.info.episode_length[i] = steps;
+                    }
+                    // ---------------- spawn (environment.py:375-567)
+                    const bool rbuf = a.reset_noise != nullptr;
+                    float u[10];
+                    if (rbuf) {
+#pragma unroll
+                        for (int k = 0; k < 10; ++k) u[k] = RN[k * N];
+                    } else {
+                        uint4 x0 = rng.raw(RS_RESET_U0), x1 = rng.raw(RS_RESET_U1), x2 = rng.raw(RS_RESET_U2);
+                        u[0] = u01(x0.x); u[1] = u01(x0.y); u[2] = u01(x0.z); u[3] = u01(x0.w);
+                        u[4] = u01(x1.x); u[5] = u01(x1.y); u[6] = u01(x1.z); u[7] = u01(x1.w);
+                        u[8] = u01(x2.x); u[9] = u01(x2.y);
+                    }
+                    const V3 tp = v3(c.target[0], c.target[1], c.target[2]);
+                    if (HAS(HLX_F_SPHERICAL)) {                                     // :390-406
+                        float radius = c.mis_radius[0] + (c.mis_radius[1] - c.mis_radius[0]) * u[0];
+                        float az = (c.mis_az[0] + (c.mis_az[1] - c.mis_az[0]) * u[1]) * 0.017453292519943295f;
+                        float el = (c.mis_el[0] + (c.mis_el[1] - c.mis_el[0]) * u[2]) * 0.017453292519943295f;
+                        float ce = cosf(el);
+                        mpos = tp + v3(radius * ce * cosf(az), radius * ce * sinf(az), radius * sinf(el));
+                    } else {                                                        // :409
+                        mpos = v3(c.mis_lo[0] + c.mis_span[0] * u[0], c.mis_lo[1] + c.mis_span[1] * u[1],
+                                  c.mis_lo[2] + c.mis_span[2] * u[2]);
+                    }
+                    float speed = c.mis_speed[0] + (c.mis_speed[1] - c.mis_speed[0]) * u[3]; // :415
+                    V3 tt = tp - mpos;
+                    float ttd = norm(tt);
+                    mvel = (ttd > 1e-6f) ? tt * (1.0f / ttd) * speed : v3(0.f, 0.f, 0.f); // :418-423
+                    ipos = v3(c.int_lo[0] + c.int_span[0] * u[4], c.int_lo[1] + c.int_span[1] * u[5],
+                              c.int_lo[2] + c.int_span[2] * u[6]);                  // :445
+                    V3 rel0 = mpos - ipos;
+                    float reld = norm(rel0);
+                    if (HAS(HLX_F_TOWARD_MISSILE) && reld > 1e-6f)                  // :452-462
+                        ivel = rel0 * (1.0f / reld) * (c.int_speed[0] + (c.int_speed[1] - c.int_speed[0]) * u[7]);
+                    else                                                            // :467
+                        ivel = v3(c.ivel_lo[0] + c.ivel_span[0] * u[7], c.ivel_lo[1] + c.ivel_span[1] * u[8],
+                                  c.ivel_lo[2] + c.ivel_span[2] * u[9]);
+                    q = Quat{1.f, 0.f, 0.f, 0.f};                                   // :489-530 rotate +Z onto the LOS
+                    if (reld > 1e-6f) {
+                        V3 fd = rel0 * (1.0f / reld);
+                        float axl = sqrtf(fd.x * fd.x + fd.y * fd.y);
+                        if (axl > 1e-6f) {
+                            float half = 0.5f * acosf(clampf(fd.z, -1.f, 1.f));
+                            float sh = sinf(half) / axl;
+                            q = Quat{cosf(half), -fd.y * sh, fd.x * sh, 0.f};
+                        } else if (!(fd.z > 0.f)) q = Quat{0.f, 1.f, 0.f, 0.f};
+                    }
+                    on_delay = c.o_delay;                                           // constructor value (core.py:292-293)
+                    fuel = 100.f;                                                   // :537
+                    wind = v3(c.base_wind[0], c.base_wind[1], c.base_wind[2]);       // :542
+                    thrust_act = v3(0.f, 0.f, 0.f);                                 // :549
+                    if (HAS(HLX_F_DOMAIN_RAND)) {                                   // :552-562, physics_randomizer.py
+                        float zt, zd, zm, zs;
+                        if (rbuf) { zt = RN[20 * N]; zd = RN[21 * N]; zm = RN[22 * N]; zs = RN[23 * N]; }
+                        else {
+                            // draws 1..4 of the 13 (the others never reach the path): temperature, drag, mach, delay
+                            float z0_; rng.normals4(RS_DR0, z0_, zt, zd, zm);
+                            float z1_, z2_, z3_; rng.normals4(RS_DR1, zs, z1_, z2_, z3_);
+                        }
+                        if (HAS(HLX_F_ATMOSPHERE)) T0 += c.dr_var[1] * zt;          // :258-261 (accumulates)
+                        if (HAS(HLX_F_MACH_DRAG)) {                                 // :270-280
+                            dp.base_cd = 0.3f * clampf(1.0f + c.dr_var[2] * zd, 0.1f, 3.0f);
+                            dp.peak = 3.0f * clampf(1.0f + c.dr_var[3] * zm, 0.1f, 3.0f);
+                        }
+                        if (c.o_delay > 0)                                          // :289-297
+                            on_delay = min(10, max(1, (int)(3.0f * clampf(1.0f + c.dr_var[4] * zs, 0.1f, 3.0f))));
+                    }
+                    steps = 0; ep_return = 0.f;                                     // :565-566
+                    kf_init = false;                                                // core.py:65-69
+                    kxp = v3(0.f, 0.f, 0.f); kxv = kxp;
+                    p_pp = 1000.f; p_pv = 0.f; p_vp = 0.f; p_vv = 1000.f;
+                    prev_distance = reld; last_distance = reld; min_distance = reld; // :579-589
+                    worsening = 0; crossed = false;
+                }
+            }
+            if (act) {
+                // ======================================================== core.py:511-691 radar detection
+                float n_on, n_g, n_dl;
+                V3 n_gp, n_gv;
+                const bool from_buf = (pass == 0) ? noise_buf : (a.reset_noise != nullptr);
+                if (from_buf) {
+                    const float* B = (pass == 0) ? (SN + 11 * N) : (RN + 10 * N);
+                    n_on = B[0]; n_g = B[1 * N]; n_gp = v3(B[2 * N], B[3 * N], B[4 * N]);
+                    n_gv = v3(B[5 * N], B[6 * N], B[7 * N]); n_dl = B[8 * N];
+                } else {
+                    uint4 x = rng.raw(pass == 0 ? RS_STEP_U : RS_RESET_OBS_U);
+                    n_on = u01(x.x); n_g = u01(x.y); n_dl = u01(x.z);
+                    n_gp = n_gv = v3(0.f, 0.f, 0.f);   // drawn below, only if the ground radar detects
+                }
+                V3 rel = mpos - ipos;
+                float range = norm(rel);
+                bool on_det = !(range > c.radar_range);                             // :539
+                V3 fwd = forward_vec(q);
+                {
+                    V3 tom = rel * (1.0f / (range + 1e-6f));                        // :546
+                    float beam_angle = acosf(clampf(dot(fwd, tom), -1.f, 1.f));     // :547
+                    if (beam_angle > a.half_beam) on_det = false;                   // :553
+                }
+                if (on_det) {                                                       // :559-566
+                    float aq = c.radar_quality * (1.0f - (range / c.radar_range) * 0.5f) * a.on_rel;
+                    if (n_on > aq) on_det = false;
+                }
+                V3 d_on = rel;
+                bool d_on_det = on_det;
+                if (c.o_delay > 0) {                                                // :576-588 onboard delay ring
+                    on_sample = make_float4(rel.x, rel.y, rel.z, on_det ? 1.f : 0.f);
+                    d_on = v3(0.f, 0.f, 0.f); d_on_det = false;
+                    if (pass == 0 && steps >= on_delay) {
+                        int slot = (int)((t + (unsigned long long)(o_cap - on_delay)) % (unsigned long long)o_cap);
+                        float4 s = a.oring[(size_t)slot * N + i];
+                        d_on = v3(s.x, s.y, s.z); d_on_det = s.w != 0.f;
+                    }
+                }
+                // ---- ground radar (core.py:368-438)
+                bool g_det = false;
+                V3 g_pos = v3(0.f, 0.f, 0.f), g_vel = g_pos;
+                float g_q = 0.f;
+                const V3 gp = v3(c.ground_pos[0], c.ground_pos[1], c.ground_pos[2]);
+                if (HAS(HLX_F_GROUND)) {
+                    V3 g2m = mpos - gp;
+                    float grange = norm(g2m);
+                    g_det = !(grange > c.g_max_range);                              // :396
+                    if (g_det && grange > 1e-6f) {                                  // :401-406
+                        float el = asinf(clampf(g2m.z / grange, -1.f, 1.f));
+                        if (el < c.g_min_elev || el > c.g_max_elev) g_det = false;
+                    }
+                    if (mpos.z < 50.f) g_det = false;                               // :409
+                    if (g_det) {                                                    // :413-418
+                        float dpq = c.g_base_q * (1.0f - (grange / c.g_max_range) * 0.4f) * c.weather * a.g_rel;
+                        if (n_g > dpq) g_det = false;
+                        else {
+                            if (!from_buf) {
+                                float w0_, w1_;
+                                rng.normals4(pass == 0 ? RS_GPOS : RS_RESET_GPOS, n_gp.x, n_gp.y, n_gp.z, w0_);
+                                rng.normals4(pass == 0 ? RS_GVEL : RS_RESET_GVEL, n_gv.x, n_gv.y, n_gv.z, w1_);
+                            }
+                            g_pos = rel + n_gp * c.g_range_acc;                     // :422-428
+                            g_vel = (mvel - ivel) + n_gv * c.g_vel_acc;             // :429
+                            g_q = dpq;
+                        }
+                    }
+                }
+                V3 d_gp = g_pos, d_gv = g_vel;
+                float d_gq = g_q;
+                bool d_g_det = g_det;
+                if (HAS(HLX_F_GROUND) && c.g_delay > 0) {                           // :609-627 ground delay ring
+                    g_s0 = make_float4(g_pos.x, g_pos.y, g_pos.z, g_q);
+                    g_s1 = make_float4(g_vel.x, g_vel.y, g_vel.z, 0.f);
+                    d_gp = v3(0.f, 0.f, 0.f); d_gv = d_gp; d_gq = 0.f; d_g_det = false;
+                    if (pass == 0 && steps >= c.g_delay) {
+                        int slot = (int)((t + 1ull) % (unsigned long long)g_cap);   // == (t - g_delay) mod g_cap
+                        const float4* R = a.gring + ((size_t)slot * 2) * N + i;
+                        float4 s0 = R[0], s1 = R[N];
+                        d_gp = v3(s0.x, s0.y, s0.z); d_gq = s0.w; d_gv = v3(s1.x, s1.y, s1.z);
+                        d_g_det = g_det;                                            // :626 CURRENT flag (reference quirk)
+                    }
+                }
+                // ---- datalink (core.py:440-474)
+                float datalink = 0.f;
+                if (HAS(HLX_F_GROUND)) {
+                    float lr = norm(ipos - gp);
+                    if (!(lr > c.max_datalink) && !(n_dl < c.packet_loss)) {
+                        float x = lr / c.max_datalink;
+                        float dop = 1.0f - fminf(norm(ivel) / 1000.f, 0.3f);
+                        datalink = clampf((1.0f - x * x) * dop * 0.95f, 0.f, 1.f);
+                    }
+                }
+                // ---- fusion confidence (core.py:476-509)
+                const float on_q = d_on_det ? c.radar_quality : 0.f;
+                float fusion;
+                if (!d_on_det && !d_g_det) fusion = 0.f;
+                else if (!d_g_det) fusion = on_q * 0.5f;
+                else if (!d_on_det) fusion = d_gq * 0.6f;
+                else {
+                    float agree = 1.0f - fminf(norm(d_on - d_gp) / 200.f, 1.0f);
+                    fusion = clampf(0.35f * on_q + 0.50f * d_gq + 0.15f * agree, 0.f, 1.f);
+                }
+                if (pass == 0) det_bits = (d_on_det ? 32u : 0u) | (d_g_det ? 64u : 0u);
+
+                // ======================================================== core.py:693-1032 compute()
+                bool have_track;
+                V3 frp = v3(0.f, 0.f, 0.f), frv = frp;
+                if (d_on_det || d_g_det) {                                          // :732-759
+                    V3 fused;
+                    if (d_on_det && d_g_det) fused = (d_on * c.radar_quality + d_gp * d_gq) * (1.0f / (c.radar_quality + d_gq));
+                    else if (d_on_det) fused = d_on;
+                    else fused = d_gp;
+                    V3 z = ipos + fused;                                            // :749
+                    if (!kf_init) { kxp = z; kxv = v3(0.f, 0.f, 0.f); kf_init = true; } // core.py:93-96
+                    else {                                                          // core.py:98-116 on 2x2 blocks
+                        float sinv = 1.0f / (p_pp + 400.f);
+                        float kp = p_pp * sinv, kv = p_vp * sinv;
+                        V3 y = z - kxp;
+                        kxp = kxp + y * kp;
+                        kxv = kxv + y * kv;
+                        float omk = 1.0f - kp;
+                        float npp = omk * p_pp, npv = omk * p_pv;
+                        float nvp = p_vp - kv * p_pp, nvv = p_vv - kv * p_pv;
+                        p_pp = npp; p_pv = npv; p_vp = nvp; p_vv = nvv;
+                    }
+                    have_track = true;
+                } else {                                                            // :760-774
+                    if (kf_init) {                                                  // core.py:80-89 predict
+                        kxp = kxp + kxv * c.dt;
+                        float a_pp = p_pp + c.dt * p_vp, a_pv = p_pv + c.dt * p_vv;
+                        p_pp = (a_pp + a_pv * c.dt) + c.q11;
+                        p_pv = a_pv + c.q12;
+                        p_vp = (p_vp + p_vv * c.dt) + c.q12;
+                        p_vv = p_vv + c.q22;
+                    }
+                    have_track = kf_init;
+                }
+                if (have_track) { frp = kxp - ipos; frv = kxv - ivel; }
+                const float inv_mr = 1.0f / c.max_range, inv_mv = 1.0f / c.max_velocity;
+                if (have_track) {                                                   // :778-906
+                    float rrange = norm(frp);
+                    float closing = -dot(frp, frv) / (rrange + 1e-6f);              // :786
+                    if (HAS(HLX_F_OBS_LOS)) {                                       // :791-868
+                        row[0] = clampf(rrange * inv_mr, 0.f, 1.f);
+                        row[1] = clampf(closing * inv_mv, -1.f, 1.f);
+                        V3 lu = (rrange > 1e-6f) ? frp * (1.0f / rrange) : v3(1.f, 0.f, 0.f);
+                        V3 rate = (frv - lu * closing) * (1.0f / (rrange + 1e-6f)); // :810-811
+                        V3 h, v;
+                        los_basis(lu, h, v);
+                        row[2] = clampf(dot(rate, h) * 2.0f, -1.f, 1.f);            // :844-845 (/0.5)
+                        row[3] = clampf(dot(rate, v) * 2.0f, -1.f, 1.f);
+                        float ivm = norm(ivel);
+                        row[4] = (ivm > 1e-6f) ? dot(ivel * (1.0f / ivm), lu) : 0.f; // :852-858
+                        V3 tv = frv + ivel;                                         // :861
+                        float tvm = norm(tv);
+                        row[5] = (tvm > 1e-6f) ? -dot(tv * (1.0f / tvm), lu) : 0.f;
+                        row[6] = clampf(ivm * inv_mv, 0.f, 1.f);                    // :924-925
+                        row[7] = clampf(dot(ivel, h) * inv_mv, -1.f, 1.f);          // :948-953
+                        row[8] = clampf(dot(ivel, v) * inv_mv, -1.f, 1.f);
+                    } else if (HAS(HLX_F_OBS_BODY)) {                               // :870-876
+                        V3 r = right_vec(q), up = up_vec(q);
+                        row[0] = clampf(dot(frp, fwd) * inv_mr, -1.f, 1.f);
+                        row[1] = clampf(dot(frp, r) * inv_mr, -1.f, 1.f);
+                        row[2] = clampf(dot(frp, up) * inv_mr, -1.f, 1.f);
+                        row[3] = clampf(dot(frv, fwd) * inv_mv, -1.f, 1.f);
+                        row[4] = clampf(dot(frv, r) * inv_mv, -1.f, 1.f);
+                        row[5] = clampf(dot(frv, up) * inv_mv, -1.f, 1.f);
+                    } else {                                                        // :878-882
+                        row[0] = clampf(frp.x * inv_mr, -1.f, 1.f); row[1] = clampf(frp.y * inv_mr, -1.f, 1.f);
+                        row[2] = clampf(frp.z * inv_mr, -1.f, 1.f); row[3] = clampf(frv.x * inv_mv, -1.f, 1.f);
+                        row[4] = clampf(frv.y * inv_mv, -1.f, 1.f); row[5] = clampf(frv.z * inv_mv, -1.f, 1.f);
+                    }
+                    row[13] = (closing > 0.f) ? clampf(1.0f - (rrange / closing) / 100.f, -1.f, 1.f) : -1.f; // :885-889
+                    float tq = clampf(1.0f - (p_pp + p_pp + p_pp) / 10000.f, 0.f, 1.f); // :892-893 trace of 3 equal blocks
+                    if (d_on_det) tq *= c.radar_quality;                            // :894-895
+                    row[14] = tq;
+                    row[15] = clampf(closing * inv_mv, -1.f, 1.f);                  // :899
+                    row[16] = (rrange > 1e-6f) ? dot(fwd, frp) / rrange : 1.0f;     // :902-906
+                } else {                                                            // :907-917
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) row[k] = -2.0f;
+                    row[13] = -1.0f; row[14] = 0.f; row[15] = 0.f; row[16] = 0.f;
+                    if (HAS(HLX_F_OBS_LOS)) { row[6] = clampf(norm(ivel) * inv_mv, 0.f, 1.f); row[7] = 0.f; row[8] = 0.f; }
+                }
+                if (HAS(HLX_F_OBS_BODY)) {                                          // :959-962
+                    V3 r = right_vec(q), up = up_vec(q);
+                    row[6] = clampf(dot(ivel, fwd) * inv_mv, -1.f, 1.f);
+                    row[7] = clampf(dot(ivel, r) * inv_mv, -1.f, 1.f);
+                    row[8] = clampf(dot(ivel, up) * inv_mv, -1.f, 1.f);
+                } else if (!HAS(HLX_F_OBS_LOS)) {                                   // :964
+                    row[6] = clampf(ivel.x * inv_mv, -1.f, 1.f); row[7] = clampf(ivel.y * inv_mv, -1.f, 1.f);
+                    row[8] = clampf(ivel.z * inv_mv, -1.f, 1.f);
+                }
+                if (HAS(HLX_F_OBS_BODY) || HAS(HLX_F_OBS_LOS)) { row[9] = 0.f; row[10] = 0.f; row[11] = 0.f; } // :967-970
+                else {                                                              // :973-974, core.py:1103-1121
+                    const float inv_pi = 0.3183098861837907f;
+                    row[9] = atan2f(2.f * (q.w * q.x + q.y * q.z), 1.f - 2.f * (q.x * q.x + q.y * q.y)) * inv_pi;
+                    row[10] = asinf(clampf(2.f * (q.w * q.y - q.z * q.x), -1.f, 1.f)) * inv_pi;
+                    row[11] = atan2f(2.f * (q.w * q.z + q.x * q.y), 1.f - 2.f * (q.y * q.y + q.z * q.z)) * inv_pi;
+                }
+                row[12] = clampf(fuel / 100.f, 0.f, 1.f);                           // :977
+                if (d_g_det && datalink > 0.1f) {                                   // :980-1018
+                    if (HAS(HLX_F_OBS_LOS)) {
+                        float gr = norm(d_gp);
+                        float gc = -dot(d_gp, d_gv) / (gr + 1e-6f);
+                        row[17] = clampf(gr * inv_mr, 0.f, 1.f);
+                        row[18] = clampf(gc * inv_mv, -1.f, 1.f);
+                        row[19] = (gr > 1e-6f) ? clampf(norm(d_gv - d_gp * (gc / gr)) / gr * 2.0f, 0.f, 1.f) : 0.f;
+                        row[20] = 0.f; row[21] = 0.f; row[22] = 0.f;
+                    } else if (HAS(HLX_F_OBS_BODY)) {
+                        V3 r = right_vec(q), up = up_vec(q);
+                        row[17] = clampf(dot(d_gp, fwd) * inv_mr, -1.f, 1.f); row[18] = clampf(dot(d_gp, r) * inv_mr, -1.f, 1.f);
+                        row[19] = clampf(dot(d_gp, up) * inv_mr, -1.f, 1.f); row[20] = clampf(dot(d_gv, fwd) * inv_mv, -1.f, 1.f);
+                        row[21] = clampf(dot(d_gv, r) * inv_mv, -1.f, 1.f); row[22] = clampf(dot(d_gv, up) * inv_mv, -1.f, 1.f);
+                    } else {
+                        row[17] = clampf(d_gp.x * inv_mr, -1.f, 1.f); row[18] = clampf(d_gp.y * inv_mr, -1.f, 1.f);
+                        row[19] = clampf(d_gp.z * inv_mr, -1.f, 1.f); row[20] = clampf(d_gv.x * inv_mv, -1.f, 1.f);
+                        row[21] = clampf(d_gv.y * inv_mv, -1.f, 1.f); row[22] = clampf(d_gv.z * inv_mv, -1.f, 1.f);
+                    }
+                    row[23] = d_gq;
+                } else {                                                            // :1019-1024
+#pragma unroll
+                    for (int k = 17; k < 23; ++k) row[k] = -2.0f;
+                    row[23] = 0.f;
+                }
+                row[24] = datalink;                                                 // :1027
+                row[25] = fusion;                                                   // :1030
+            }
+        }
+
+        // ---------------------------------------------------------------------- store state + rings
+        if (MODE == 0 || done) {
+            packed = (uint32_t)steps | ((uint32_t)worsening << 13) | ((uint32_t)crossed << 26) |
+                     ((uint32_t)kf_init << 27) | ((uint32_t)on_delay << 28);
+            A[G_IPOS * N] = make_float4(ipos.x, ipos.y, ipos.z, fuel);
+            A[G_IVEL * N] = make_float4(ivel.x, ivel.y, ivel.z, prev_distance);
+            A[G_QUAT * N] = make_float4(q.w, q.x, q.y, q.z);
+            A[G_MPOS * N] = make_float4(mpos.x, mpos.y, mpos.z, min_distance);
+            A[G_MVEL * N] = make_float4(mvel.x, mvel.y, mvel.z, last_distance);
+            A[G_WIND * N] = make_float4(wind.x, wind.y, wind.z, __uint_as_float(packed));
+            A[G_KFP * N] = make_float4(kxp.x, kxp.y, kxp.z, p_pp);
+            A[G_KFV * N] = make_float4(kxv.x, kxv.y, kxv.z, p_pv);
+            A[G_MISC * N] = make_float4(p_vp, p_vv, ep_return, T0);
+            if (HAS(HLX_F_THRUST_LAG)) A[G_THRUST * N] = make_float4(thrust_act.x, thrust_act.y, thrust_act.z, 0.f);
+            if (HAS(HLX_F_DOMAIN_RAND)) A[G_DR * N] = make_float4(dp.base_cd, dp.peak, 0.f, 0.f);
+            if (c.o_delay > 0) a.oring[(size_t)(t % (unsigned long long)o_cap) * N + i] = on_sample;
+            if (HAS(HLX_F_GROUND) && c.g_delay > 0) {
+                float4* R = a.gring + ((size_t)(t % (unsigned long long)g_cap) * 2) * N + i;
+                R[0] = g_s0; R[N] = g_s1;
+            }
+        }
+        if (MODE == 0) {
+            a.reward[i] = reward;
+            a.term[i] = terminated ? 1 : 0;
+            a.trunc[i] = truncated ? 1 : 0;
+            if (a.info.distance) a.info.distance[i] = distance;
+            if (a.info.min_distance) a.info.min_distance[i] = min_distance;
+            if (a.info.fuel) a.info.fuel[i] = fuel;
+            if (a.info.flags)
+                a.info.flags[i] = (uint8_t)((intercepted ? 1u : 0u) | (hit_target ? 2u : 0u) | (fuze ? 4u : 0u) |
+                                            (clamped ? 8u : 0u) | (crossed ? 16u : 0u) | det_bits);
+        }
+    }
+
+    // -------------------------------------------------------------------------- done-mask compaction
+    if (MODE == 0 && a.done_idx) {
+        const unsigned long long m = __ballot(live && done);
+        if (m) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(a.done_cnt + (int)(t & 1ull), __popcll(m));
+            base = __shfl(base, 0);
+            if (live && done) a.done_idx[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        }
+        if (blockIdx.x == 0 && lane == 0) a.done_cnt[(int)((t + 1ull) & 1ull)] = 0;   // arm the other counter
+    }
+
+    // -------------------------------------------------------------------------- observation tile -> [N][26]
+    if (a.obs) {
+        __syncthreads();
+        const int rows = min(64, n - blockIdx.x * 64);
+        float* dst = a.obs + (size_t)blockIdx.x * 64 * HLX_OBS_DIM;
+        if (MODE == 0) {
+            if (rows == 64) {
+                const float4* src4 = reinterpret_cast<const float4*>(tile);
+                float4* dst4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+                for (int r = 0; r < 7; ++r) {
+                    int j = lane + 64 * r;
+                    if (j < 64 * HLX_OBS_DIM / 4) dst4[j] = src4[j];
+                }
+            } else {
+                for (int j = lane; j < rows * HLX_OBS_DIM; j += 64) dst[j] = tile[j];
+            }
+        } else if (live && done) {
+            for (int k = 0; k < HLX_OBS_DIM; ++k) dst[lane * HLX_OBS_DIM + k] = row[k];
+        }
+    }
+}
+
+}  // namespace
+
+// host side of the C ABI
+#include "hlx_host.inc"

@@ -1,0 +1,360 @@
+"""Drop-in vector environment over the HIP step kernel.
+
+Presents the reference's env surface for N environments at once:
+
+* the Stable-Baselines3 ``VecEnv`` contract the reference's trainers consume
+  (rl_system/scripts/train_flat_ppo.py:371-399, train_hrl_pretrain.py:349-387): ``num_envs``,
+  ``observation_space``, ``action_space``, ``reset()``, ``step_async()/step_wait()`` with auto-reset,
+  ``infos[i]['terminal_observation']``, ``infos[i]['TimeLimit.truncated']``, Monitor-style
+  ``infos[i]['episode']``, ``env_method``, ``get_attr``, ``set_attr``, ``seed``, ``close``;
+* a gymnasium ``VectorEnv``-style ``step_torch()`` that returns PyTorch-ROCm tensors without any
+  host round trip (obs, reward, terminated, truncated, info-dict-of-tensors).
+
+All compute happens in ``libhlx.so`` (one fused HIP kernel per step); torch only owns the I/O
+buffers and the stream.  There is no CPU fallback: without a GPU / the HIP library construction fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .config import ResolvedConfig, resolve_config
+
+try:  # gymnasium is optional (absent in the build image); only `spaces.Box` is needed
+    from gymnasium import spaces as _spaces
+
+    def _box(low, high, shape):
+        return _spaces.Box(low=low, high=high, shape=shape, dtype=np.float32)
+except Exception:  # pragma: no cover - exercised where gymnasium is missing
+    class _Box:
+        def __init__(self, low, high, shape, dtype=np.float32):
+            self.low = np.full(shape, low, dtype)
+            self.high = np.full(shape, high, dtype)
+            self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+
+        def sample(self):
+            return np.random.uniform(self.low, self.high).astype(self.dtype)
+
+        def contains(self, x):
+            x = np.asarray(x)
+            return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+        def __repr__(self):
+            return f"Box({self.low.flat[0]}, {self.high.flat[0]}, {self.shape}, {self.dtype})"
+
+    def _box(low, high, shape):
+        return _Box(low, high, shape)
+
+
+class _ObservationGeneratorView:
+    """`get_attr('observation_generator')[i]` (train_flat_ppo.py:224-232): curriculum-controlled radar knobs."""
+
+    def __init__(self, venv):
+        self._v = venv
+
+    def _cur(self):
+        return self._v.curriculum()
+
+    radar_beam_width = property(lambda s: s._cur()["beam_width"])
+    onboard_detection_reliability = property(lambda s: s._cur()["onboard_reliability"])
+    ground_detection_reliability = property(lambda s: s._cur()["ground_reliability"])
+    measurement_noise_level = property(lambda s: s._cur()["noise_level"])
+
+
+class LazyInfos(Sequence):
+    """`infos` of one vec step: behaves like a list of N dicts, builds a dict only when indexed.
+
+    Building 65 536 Python dicts per step would cost more than the step itself."""
+
+    def __init__(self, n, done_rows, host):
+        self._n, self._done, self._h = n, done_rows, host
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        h = self._h
+        flags = int(h["flags"][i])
+        d: Dict[str, Any] = {
+            "distance": float(h["distance"][i]), "min_distance": float(h["min_distance"][i]),
+            "fuel_remaining": float(h["fuel"][i]), "intercepted": bool(flags & 1),
+            "missile_hit_target": bool(flags & 2), "proximity_fuze_triggered": bool(flags & 4),
+            "clamped": bool(flags & 8), "crossed_threshold": bool(flags & 16), "radar_detected": bool(flags & 32),
+            "ground_radar_detected": bool(flags & 64),
+            "TimeLimit.truncated": bool(h["truncated"][i] and not h["terminated"][i]),
+        }
+        row = self._done.get(i)
+        if row is not None:
+            d["terminal_observation"] = h["terminal_obs"][row]
+            d["episode"] = {"r": float(h["ep_return"][row]), "l": int(h["ep_length"][row]),
+                            "t": round(time.time() - h["t_start"], 6)}
+        return d
+
+    def done_items(self):
+        """(env index, info dict) for the envs that finished this step - what callbacks iterate over."""
+        return [(i, self[i]) for i in sorted(self._done)]
+
+
+class HlynrVecEnv:
+    """N intercept environments on one MI355X, stepped by one fused HIP kernel per call."""
+
+    metadata = {"render_modes": []}
+
+    def __init__(self, config: Optional[Dict[str, Any]] = None, num_envs: int = 16, device: int = 0, seed: int = 0,
+                 env_id_offset: int = 0, resolved: Optional[ResolvedConfig] = None):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("HlynrVecEnv needs a ROCm GPU: the step runs in a HIP kernel and has no CPU fallback")
+        self._torch = torch
+        self.config = config or {}
+        self.rc = resolved if resolved is not None else resolve_config(self.config)
+        self.num_envs = int(num_envs)
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.observation_space = _box(-2.0, 1.0, (_lib.OBS_DIM,))     # environment.py:192-194
+        self.action_space = _box(-1.0, 1.0, (_lib.ACT_DIM,))          # environment.py:195-197
+        self._lib = _lib.load()
+        self._cfg = _lib.make_hlx_config(self.rc)
+        self._h = C.c_void_p()
+        _lib.check(self._lib.hlx_create(C.byref(self._cfg), self.num_envs, self.device_index, int(seed),
+                                        int(env_id_offset), C.byref(self._h)))
+        n, dev = self.num_envs, self.device
+        self.obs = torch.zeros((n, _lib.OBS_DIM), dtype=torch.float32, device=dev)
+        self.reward = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.terminated = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.truncated = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.terminal_obs = torch.zeros((n, _lib.OBS_DIM), dtype=torch.float32, device=dev)
+        self.done_idx = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.n_done = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.info = dict(distance=torch.zeros(n, device=dev), min_distance=torch.zeros(n, device=dev),
+                         fuel=torch.zeros(n, device=dev), flags=torch.zeros(n, dtype=torch.uint8, device=dev),
+                         episode_return=torch.zeros(n, device=dev),
+                         episode_length=torch.zeros(n, dtype=torch.int32, device=dev))
+        self._info_soa = _lib.HlxInfoSoa(*(self.info[k].data_ptr() for k in
+                                           ("distance", "min_distance", "fuel", "flags", "episode_return",
+                                            "episode_length")))
+        self._actions_dev = torch.zeros((n, _lib.ACT_DIM), dtype=torch.float32, device=dev)
+        self._pending = None
+        self._t_start = time.time()
+        self._closed = False
+        self._noise = None
+        self.training_step_count = 0
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if not self._closed and self._h:
+            self._torch.cuda.synchronize(self.device)
+            self._lib.hlx_destroy(self._h)
+            self._closed = True
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def kernel_variant(self) -> str:
+        return self._lib.hlx_kernel_variant(self._h).decode()
+
+    # ------------------------------------------------------------------ torch / gymnasium-vector style API
+    def reset_torch(self, mask=None):
+        """Reset all envs (or those where `mask` is non-zero); returns the device obs tensor [N, 26]."""
+        mptr = None
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=self._torch.uint8).contiguous()
+            mptr = mask.data_ptr()
+        _lib.check(self._lib.hlx_reset(self._h, mptr, self.obs.data_ptr(), self._stream()))
+        return self.obs
+
+    def step_torch(self, actions, want_done_list: bool = False):
+        """One vec step on device tensors.  `actions`: float32 [N, 6] on this device.
+
+        Returns (obs, reward, terminated, truncated, info) - all torch tensors living on the GPU; they are
+        overwritten by the next call (clone what must survive)."""
+        t = self._torch
+        if actions.dtype != t.float32 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(device=self.device, dtype=t.float32).contiguous()
+        if tuple(actions.shape) != (self.num_envs, _lib.ACT_DIM):
+            raise ValueError(f"actions must have shape ({self.num_envs}, {_lib.ACT_DIM}), got {tuple(actions.shape)}")
+        di = self.done_idx.data_ptr() if want_done_list else None
+        nd = self.n_done.data_ptr() if want_done_list else None
+        _lib.check(self._lib.hlx_step(self._h, actions.data_ptr(), self.obs.data_ptr(), self.reward.data_ptr(),
+                                      self.terminated.data_ptr(), self.truncated.data_ptr(),
+                                      self.terminal_obs.data_ptr(), di, nd, C.byref(self._info_soa), self._stream()))
+        info = dict(self.info)
+        info["terminal_observation"] = self.terminal_obs
+        if want_done_list:
+            info["done_idx"], info["n_done"] = self.done_idx, self.n_done
+        return self.obs, self.reward, self.terminated, self.truncated, info
+
+    def rollout_torch(self, action_tape, out_slots: int = 1):
+        """T steps from a pre-supplied tape [T, N, 6] with one launch per step issued from C
+        (open-loop evaluation / benchmark path).  Returns (obs, reward, terminated, truncated) ring buffers."""
+        t = self._torch
+        T = int(action_tape.shape[0])
+        assert tuple(action_tape.shape[1:]) == (self.num_envs, _lib.ACT_DIM) and action_tape.dtype == t.float32
+        assert action_tape.is_contiguous() and action_tape.device == self.device
+        key = ("ro", out_slots)
+        if getattr(self, "_ro_key", None) != key:
+            n, dev = self.num_envs, self.device
+            self._ro = (t.zeros((out_slots, n, _lib.OBS_DIM), device=dev), t.zeros((out_slots, n), device=dev),
+                        t.zeros((out_slots, n), dtype=t.uint8, device=dev),
+                        t.zeros((out_slots, n), dtype=t.uint8, device=dev))
+            self._ro_key = key
+        o, r, te, tr = self._ro
+        _lib.check(self._lib.hlx_rollout(self._h, action_tape.data_ptr(), T, out_slots, o.data_ptr(), r.data_ptr(),
+                                         te.data_ptr(), tr.data_ptr(), self._stream()))
+        return o, r, te, tr
+
+    # ------------------------------------------------------------------ SB3 VecEnv API (numpy at the boundary)
+    def reset(self):
+        self._t_start = time.time()
+        return self.reset_torch().cpu().numpy()
+
+    def step_async(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        if a.shape != (self.num_envs, _lib.ACT_DIM):
+            raise ValueError(f"actions must have shape ({self.num_envs}, {_lib.ACT_DIM}), got {a.shape}")
+        self._actions_dev.copy_(self._torch.from_numpy(a))
+        self._pending = self.step_torch(self._actions_dev, want_done_list=True)
+
+    def step_wait(self):
+        if self._pending is None:
+            raise RuntimeError("step_wait() called without step_async()")
+        obs, rew, term, trunc, info = self._pending
+        self._pending = None
+        obs_h = obs.cpu().numpy()
+        rew_h = rew.cpu().numpy()
+        term_h = term.cpu().numpy().astype(bool)
+        trunc_h = trunc.cpu().numpy().astype(bool)
+        dones = term_h | trunc_h
+        n_done = int(self.n_done.item())
+        host = dict(terminated=term_h, truncated=trunc_h, distance=info["distance"].cpu().numpy(),
+                    min_distance=info["min_distance"].cpu().numpy(), fuel=info["fuel"].cpu().numpy(),
+                    flags=info["flags"].cpu().numpy(), t_start=self._t_start)
+        done_rows: Dict[int, int] = {}
+        if n_done:
+            idx = self.done_idx[:n_done].to(self._torch.int64)
+            idx_h = idx.cpu().numpy()
+            host["terminal_obs"] = self.terminal_obs.index_select(0, idx).cpu().numpy()
+            host["ep_return"] = self.info["episode_return"].index_select(0, idx).cpu().numpy()
+            host["ep_length"] = self.info["episode_length"].index_select(0, idx).cpu().numpy()
+            done_rows = {int(e): r for r, e in enumerate(idx_h)}
+        return obs_h, rew_h, dones, LazyInfos(self.num_envs, done_rows, host)
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def seed(self, seed: Optional[int] = None):
+        """SB3 `VecEnv.seed`: the RNG is counter-based and keyed at construction; re-keying = new env set."""
+        return [seed] * self.num_envs
+
+    def _indices(self, indices):
+        if indices is None:
+            return range(self.num_envs)
+        if isinstance(indices, int):
+            return [indices]
+        return indices
+
+    def env_method(self, method_name: str, *args, indices=None, **kwargs) -> List[Any]:
+        idx = self._indices(indices)
+        if method_name == "set_training_step_count":      # environment.py:269, called every step by the trainer
+            self.set_training_step_count(*args, **kwargs)
+            return [None] * len(idx)
+        if method_name == "get_current_intercept_radius":  # environment.py:223
+            return [self.get_current_intercept_radius()] * len(idx)
+        raise AttributeError(f"env_method({method_name!r}) is not part of the batched environment")
+
+    def get_attr(self, attr_name: str, indices=None) -> List[Any]:
+        idx = self._indices(indices)
+        if attr_name == "observation_generator":
+            return [_ObservationGeneratorView(self)] * len(idx)
+        if attr_name in ("interceptor_state", "missile_state"):
+            st = self.get_state()
+            pre = "int_" if attr_name == "interceptor_state" else "mis_"
+            out = []
+            for i in idx:
+                d = {"position": np.array(st[i].__getattribute__(pre + "pos")[:], np.float32),
+                     "velocity": np.array(st[i].__getattribute__(pre + "vel")[:], np.float32)}
+                if pre == "int_":
+                    d["orientation"] = np.array(st[i].int_quat[:], np.float32)
+                    d["fuel"] = float(st[i].fuel)
+                out.append(d)
+            return out
+        if hasattr(self, attr_name):
+            return [getattr(self, attr_name)] * len(idx)
+        raise AttributeError(attr_name)
+
+    def set_attr(self, attr_name: str, value: Any, indices=None) -> None:
+        if attr_name == "training_step_count":
+            self.set_training_step_count(value)
+        else:
+            raise AttributeError(f"set_attr({attr_name!r}) is not supported by the batched environment")
+
+    def env_is_wrapped(self, wrapper_class, indices=None) -> List[bool]:
+        return [False] * len(self._indices(indices))
+
+    # ------------------------------------------------------------------ reference env methods
+    def set_training_step_count(self, step_count: int):
+        """environment.py:269-272 - O(1): the schedules are evaluated host-side, values ride as kernel args."""
+        self.training_step_count = int(step_count)
+        _lib.check(self._lib.hlx_set_global_step(self._h, int(step_count)))
+
+    def curriculum(self) -> Dict[str, float]:
+        out = (C.c_double * 5)()
+        _lib.check(self._lib.hlx_get_curriculum(self._h, C.byref(out)))
+        return dict(intercept_radius=out[0], beam_width=out[1], onboard_reliability=out[2],
+                    ground_reliability=out[3], noise_level=out[4])
+
+    def get_current_intercept_radius(self) -> float:
+        return self.curriculum()["intercept_radius"]
+
+    # ------------------------------------------------------------------ parity / checkpoint hooks
+    def set_noise(self, step_noise=None, reset_noise=None):
+        """Parity mode: slot-major device tensors [20, N] / [32, N] replace the Philox draws (None restores)."""
+        self._noise = (step_noise, reset_noise)
+        _lib.check(self._lib.hlx_set_noise(self._h, step_noise.data_ptr() if step_noise is not None else None,
+                                           reset_noise.data_ptr() if reset_noise is not None else None))
+
+    def fill_noise(self, for_reset: bool = False):
+        """The Philox draws of the next step (or, `for_reset=True`, of a reset issued now) as slot-major
+        tensors ([20, N], [32, N])."""
+        t = self._torch
+        sn = t.zeros((_lib.STEP_SLOTS, self.num_envs), device=self.device)
+        rn = t.zeros((_lib.RESET_SLOTS, self.num_envs), device=self.device)
+        _lib.check(self._lib.hlx_fill_noise(self._h, sn.data_ptr(), rn.data_ptr(), 0 if for_reset else 1, self._stream()))
+        return sn, rn
+
+    def get_state(self):
+        arr = (_lib.HlxEnvState * self.num_envs)()
+        self._torch.cuda.synchronize(self.device)
+        _lib.check(self._lib.hlx_get_state(self._h, C.addressof(arr)))
+        return arr
+
+    def set_state(self, arr):
+        self._torch.cuda.synchronize(self.device)
+        _lib.check(self._lib.hlx_set_state(self._h, C.addressof(arr)))
+
+    def profile(self, enable: bool):
+        _lib.check(self._lib.hlx_profile(self._h, int(enable)))
+
+    def profile_read(self):
+        ms, cnt = C.c_double(), C.c_int64()
+        _lib.check(self._lib.hlx_profile_read(self._h, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value

@@ -1,0 +1,193 @@
+/*
+ * hlx.h -- C ABI of the MI355X-native batched intercept-environment step.
+ *
+ * Drop-in boundary for the hot path of RomanSlack/Hlynr_Intercept: the per-environment
+ * `InterceptEnvironment.reset()/step()` (rl_system/environment.py:353-603, :605-859) together
+ * with the observation builder (rl_system/core.py:511-1032) and the physics evaluators
+ * (rl_system/physics_models.py:40-387, rl_system/physics_randomizer.py:137-297), for N
+ * environments at once on one GPU.  Plain pointers and sizes only; no torch/numpy types.
+ *
+ * Conventions
+ *  - every `float*`/`uint8_t*`/`int32_t*` I/O argument of hlx_reset/hlx_step/hlx_rollout is a
+ *    DEVICE pointer owned by the caller (e.g. a torch ROCm tensor's data_ptr); it must stay valid
+ *    until the stream has passed the call.  `stream` is a hipStream_t (NULL = default stream).
+ *  - the library owns the struct-of-arrays state arena (one hipMalloc at hlx_create); hlx_step
+ *    allocates nothing and never synchronises, so it can be captured into a hipGraph.
+ *  - every function returns HLX_OK (0) or a negative hlx_status; hlx_last_error() gives the
+ *    message (thread-local).  HIP errors are mapped, never abort().
+ *  - one handle per device; a handle is not thread-safe, distinct handles are independent.
+ */
+#ifndef HLX_H
+#define HLX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HLX_OBS_DIM 26      /* environment.py:192-194  Box(-2, 1, (26,), float32) */
+#define HLX_ACT_DIM 6       /* environment.py:195-197  Box(-1, 1, (6,), float32)  */
+#define HLX_STEP_SLOTS 20   /* unit random draws one step may consume */
+#define HLX_RESET_SLOTS 32  /* unit random draws one reset may consume */
+#define HLX_MAX_DELAY 10    /* physics_randomizer.py:293 clamps the onboard delay to [1, 10] samples */
+#define HLX_RING_CAP (HLX_MAX_DELAY + 1)
+#define HLX_MAX_STEPS 8191  /* per-episode step counter is packed into 13 bits */
+
+typedef enum hlx_status {
+    HLX_OK = 0,
+    HLX_ERR_INVALID = -1,   /* bad argument / unsupported configuration */
+    HLX_ERR_HIP = -2,       /* a HIP runtime call failed (message has hipGetErrorString) */
+    HLX_ERR_NOMEM = -3,
+    HLX_ERR_STATE = -4      /* call not valid in the handle's current state */
+} hlx_status;
+
+/* Step-slot layout (noise injection, parity mode):
+ *   0-2 evasion N(0,1)      environment.py:1105        3-5 wind N(0,1)  environment.py:1128 / physics_models.py:372
+ *   6 gust U                physics_models.py:381      7-9 gust direction N   :382     10 gust magnitude Exp(1) :384
+ *   11 onboard detect U     core.py:563                12 ground detect U     core.py:417
+ *   13-15 ground pos N      core.py:425                16-18 ground vel N     core.py:426   19 datalink U core.py:470
+ * Reset-slot layout:
+ *   0-2 missile position U (box; or radius/azimuth/elevation, spherical) environment.py:398-409
+ *   3 missile speed U :415     4-6 interceptor position U :445     7-9 interceptor velocity U :467 (7 = speed U :461)
+ *   10 onboard U  11 ground U  12-14 ground pos N  15-17 ground vel N  18 datalink U   (first observation, :570)
+ *   19-31 domain-randomisation N x13 in draw order, physics_randomizer.py:165-214
+ */
+
+typedef enum hlx_flags {
+    HLX_F_ATMOSPHERE = 1u << 0,    /* ISA density / speed of sound      physics_models.py:154-177 */
+    HLX_F_MACH_DRAG = 1u << 1,     /* Mach-dependent Cd                 physics_models.py:197-264 */
+    HLX_F_ENH_WIND = 1u << 2,      /* boundary-layer wind + turbulence  physics_models.py:351-387 */
+    HLX_F_THRUST_LAG = 1u << 3,    /* first-order thrust response       environment.py:874-878 */
+    HLX_F_DOMAIN_RAND = 1u << 4,   /* per-episode randomisation         physics_randomizer.py:137-297 */
+    HLX_F_VALIDATION = 1u << 5,    /* nan_to_num guard                  environment.py:927-930,1111-1113 */
+    HLX_F_EVASION = 1u << 6,       /* missile evasion noise             environment.py:1103-1105 */
+    HLX_F_PRECISION = 1u << 7,     /* precision_mode reward/termination environment.py:752-767,1151-1271 */
+    HLX_F_PROX_FUZE = 1u << 8,     /* proximity fuze                    environment.py:700-717 */
+    HLX_F_GROUND = 1u << 9,        /* ground radar station present      core.py:296-320 */
+    HLX_F_SPHERICAL = 1u << 10,    /* missile spherical spawn           environment.py:390-406 */
+    HLX_F_TOWARD_MISSILE = 1u << 11, /* interceptor velocity_mode       environment.py:452-462 */
+    HLX_F_OBS_BODY = 1u << 12,     /* observation_mode body_frame       core.py:870-876 */
+    HLX_F_OBS_LOS = 1u << 13,      /* observation_mode los_frame + LOS action transform  core.py:791-868, environment.py:965-1063 */
+    HLX_F_USE_CURRICULUM = 1u << 14, /* intercept-radius curriculum     environment.py:223-234 */
+    HLX_F_RADAR_CURRICULUM = 1u << 15 /* radar curriculum dict non-empty environment.py:274-351 */
+} hlx_flags;
+
+/* Flat parameter set = the EFFECTIVE values the reference's constructor arrives at
+ * (hlynr_intercept_amd/config.py resolves a reference config dict into this). */
+typedef struct hlx_config {
+    uint32_t flags;
+    int32_t max_steps;
+    float dt, max_range, max_velocity;
+    float target_pos[3];
+    float mis_pos_lo[3], mis_pos_hi[3];
+    float mis_radius[2], mis_azimuth_deg[2], mis_elevation_deg[2], mis_speed[2];
+    float int_pos_lo[3], int_pos_hi[3], int_vel_lo[3], int_vel_hi[3], int_speed[2];
+    float subsonic_mach, supersonic_mach, transonic_peak_multiplier, supersonic_multiplier;
+    float base_wind[3], wind_variability, boundary_layer_height, turbulence_intensity, gust_scale, thrust_tau;
+    float dr_variations[13];
+    float proximity_kill_radius;
+    float radar_quality, radar_range, radar_beam_width;
+    int32_t onboard_delay;          /* samples, 0 = no onboard delay ring */
+    float ground_pos[3], ground_max_range, ground_min_elev, ground_max_elev;
+    float ground_range_accuracy, ground_velocity_accuracy, ground_base_quality;
+    float max_datalink_range, datalink_packet_loss, weather_factor;
+    int32_t ground_delay;           /* samples, 0 = no ground delay ring */
+    /* curriculum schedules, evaluated host-side in double by hlx_set_global_step */
+    double initial_radius, final_radius, curriculum_steps;
+    double rc_beam[4], rc_onboard[4], rc_ground[4], rc_noise[4]; /* {initial, final, start, end} */
+} hlx_config;
+
+/* Optional per-step side outputs (device pointers, each may be NULL = not wanted).
+ * Mirrors the keys of the reference's `info` dict that callers read (environment.py:829-857). */
+typedef struct hlx_info_soa {
+    float *distance;          /* [N] info['distance'] */
+    float *min_distance;      /* [N] info['min_distance'] */
+    float *fuel;              /* [N] info['fuel_remaining'] */
+    uint8_t *flags;           /* [N] bit0 intercepted, bit1 missile_hit_target, bit2 proximity_fuze_triggered,
+                                     bit3 clamped, bit4 crossed_threshold, bit5 onboard radar detected (delayed),
+                                     bit6 ground radar detected */
+    float *episode_return;    /* [N] written only for envs that finished this step (Monitor 'r') */
+    int32_t *episode_length;  /* [N] written only for envs that finished this step (Monitor 'l') */
+} hlx_info_soa;
+
+/* Logical per-environment state, array-of-struct, HOST memory: parity injection and checkpointing. */
+typedef struct hlx_env_state {
+    float int_pos[3], int_vel[3], int_quat[4], fuel;
+    float thrust_actual[3];
+    float mis_pos[3], mis_vel[3];
+    float wind[3];
+    float prev_distance, min_distance, last_distance;
+    int32_t steps, worsening, crossed, kf_init;
+    float kf_x[6];
+    float kf_P[4];                      /* p_pp, p_pv, p_vp, p_vv : covariance is 3 identical 2x2 blocks */
+    int32_t on_delay, on_len;
+    float on_ring[HLX_RING_CAP][4];     /* oldest -> newest : rel_pos xyz, detected(0/1) */
+    int32_t g_len;
+    float g_ring[HLX_RING_CAP][8];      /* oldest -> newest : rel_pos xyz, quality, rel_vel xyz, pad */
+    float T0, base_cd, transonic_peak;  /* constants touched by domain randomisation */
+    float ep_return;
+} hlx_env_state;
+
+typedef struct hlx_env hlx_env;
+
+/* Create N environments on `device`.  `env_id_offset` is the global index of this shard's first
+ * environment: the counter-based RNG is keyed by (seed, global env id, vec-step), so results do not
+ * depend on how environments are sharded over GPUs.  Envs are NOT reset by create. */
+int hlx_create(const hlx_config *cfg, int32_t n_envs, int32_t device, uint64_t seed, int64_t env_id_offset,
+               hlx_env **out);
+int hlx_destroy(hlx_env *env);
+
+/* environment.py:353 reset().  mask: device uint8[N] (non-zero = reset that env) or NULL = all.
+ * obs_out: device float[N][26] (rows of envs that are not reset are left untouched), may be NULL. */
+int hlx_reset(hlx_env *env, const uint8_t *mask, float *obs_out, void *stream);
+
+/* environment.py:605 step() for all N envs, with VecEnv auto-reset: an env that terminates or
+ * truncates is reset inside the same launch; `obs` then holds the first observation of the new
+ * episode and `terminal_obs[i]` (if not NULL) the last one of the finished episode.
+ * actions [N][6], obs [N][26], reward [N], terminated [N], truncated [N];
+ * done_idx/n_done (optional): compacted list of finished env indices and its length. */
+int hlx_step(hlx_env *env, const float *actions, float *obs, float *reward, uint8_t *terminated,
+             uint8_t *truncated, float *terminal_obs, int32_t *done_idx, int32_t *n_done,
+             const hlx_info_soa *info, void *stream);
+
+/* T consecutive steps from a pre-supplied action tape [T][N][6], one launch per step issued from C
+ * (benchmark / open-loop evaluation path).  Outputs of step t go to slot (t % out_slots) of
+ * obs [out_slots][N][26], reward/terminated/truncated [out_slots][N] (out_slots >= 1). */
+int hlx_rollout(hlx_env *env, const float *actions, int32_t T, int32_t out_slots, float *obs, float *reward,
+                uint8_t *terminated, uint8_t *truncated, void *stream);
+
+/* environment.py:269 set_training_step_count(): O(1) host-side; evaluates the curriculum
+ * schedules (environment.py:223-234, :274-351) and the result rides along as kernel arguments. */
+int hlx_set_global_step(hlx_env *env, int64_t global_step);
+/* out[5] = {intercept_radius, beam_width_deg, onboard_reliability, ground_reliability, noise_level} */
+int hlx_get_curriculum(hlx_env *env, double out[5]);
+
+/* Parity mode: take the random draws from caller-supplied DEVICE arrays instead of Philox.
+ * step_noise [HLX_STEP_SLOTS][N], reset_noise [HLX_RESET_SLOTS][N] (slot-major).  NULL restores Philox. */
+int hlx_set_noise(hlx_env *env, const float *step_noise, const float *reset_noise);
+/* Write the Philox draws of vec-step clock (current + clock_offset) into slot-major device arrays
+ * (every slot, whether or not it ends up being consumed): clock_offset = 1 -> what the NEXT hlx_step
+ * (and its auto-resets) will draw; clock_offset = 0 -> what an hlx_reset issued now will draw. */
+int hlx_fill_noise(hlx_env *env, float *step_noise, float *reset_noise, int32_t clock_offset, void *stream);
+
+/* Logical state export / injection (host array of n_envs hlx_env_state).  Synchronises. */
+int hlx_get_state(hlx_env *env, hlx_env_state *host_out);
+int hlx_set_state(hlx_env *env, const hlx_env_state *host_in);
+
+/* Kernel timing with HIP events recorded on the launch stream around every step kernel. */
+int hlx_profile(hlx_env *env, int32_t enable);
+int hlx_profile_read(hlx_env *env, double *total_ms, int64_t *launches); /* synchronises, then clears */
+
+int32_t hlx_num_envs(const hlx_env *env);
+int64_t hlx_vec_steps(const hlx_env *env);              /* launches so far (the RNG/ring clock) */
+const char *hlx_kernel_variant(const hlx_env *env);     /* "base", "v2dr" or "generic" */
+int32_t hlx_sizeof_config(void);
+int32_t hlx_sizeof_env_state(void);
+const char *hlx_last_error(void);
+const char *hlx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HLX_H */

@@ -1,0 +1,243 @@
+"""GPU parity tests: the HIP step (through the C ABI in libhlx.so) against
+  (1) the golden fixtures captured from the reference, and
+  (2) the CPU oracle on seeded random batches, free-running over hundreds of steps.
+
+Tolerance (BASELINE.json north_star): 1e-5 relative fp32 on next-state, observation, reward; flags
+identical.  Observations are O(1) quantities normalised by the reference itself, so their bound is
+absolute; state / reward / distance bounds are relative to max(1, |x|).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.golden_util import fixture_names, load_fixture
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5          # the bar
+OBS_ATOL = 2e-5      # |obs| <= 2; Kalman-filtered entries carry ~1e-6 of float32 noise amplified by the filter
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _make_env(rc, n, global_step=None, seed=0, offset=0):
+    from hlynr_intercept_amd.vec_env import HlynrVecEnv
+    env = HlynrVecEnv(resolved=rc, num_envs=n, seed=seed, env_id_offset=offset)
+    if global_step is not None:
+        env.set_training_step_count(global_step)
+    return env
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b) / np.maximum(1.0, np.abs(b))
+
+
+# ----------------------------------------------------------------------------------------------
+# (1) golden fixtures replayed on the GPU
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", fixture_names())
+def test_gpu_matches_reference_fixture(name):
+    torch = _torch()
+    from hlynr_intercept_amd.config import resolve_config
+
+    fx = load_fixture(name)
+    rc = resolve_config(fx["config"])
+    n = 3   # same inputs in three lanes: also checks lane independence
+    env = _make_env(rc, n, fx["global_step_or_none"])
+    dev = env.device
+    T = len(fx["action"])
+    sn_all = torch.tensor(np.nan_to_num(fx["step_noise"], nan=0.5), dtype=torch.float32, device=dev)       # [T,20]
+    sn_all = sn_all[:, :, None].expand(T, 20, n).contiguous()
+    rn0 = torch.tensor(np.nan_to_num(fx["reset_noise0"], nan=0.5), dtype=torch.float32, device=dev)[:, None].expand(32, n).contiguous()
+    if "reset_noise" in fx:
+        rn_all = torch.tensor(np.nan_to_num(fx["reset_noise"], nan=0.5), dtype=torch.float32, device=dev)
+        rn_all = rn_all[:, :, None].expand(rn_all.shape[0], 32, n).contiguous()
+    actions = torch.tensor(fx["action"], dtype=torch.float32, device=dev)[:, None, :].expand(T, n, 6).contiguous()
+
+    env.set_noise(sn_all[0], rn0)
+    obs0 = env.reset_torch().cpu().numpy()
+    assert np.max(np.abs(obs0 - fx["reset_obs0"][None])) <= OBS_ATOL
+    # forced edge cases: overwrite the kinematic state the generator tweaked after its first reset
+    st = env.get_state()
+    for i in range(n):
+        for fld in ("int_pos", "int_vel", "int_quat", "mis_pos", "mis_vel"):
+            arr = getattr(st[i], fld)
+            for k, x in enumerate(fx["init_" + fld]):
+                arr[k] = float(x)
+        st[i].fuel = float(fx["init_fuel"]); st[i].steps = int(fx["init_steps"])
+        st[i].prev_distance = float(fx["init_prev_distance"]); st[i].min_distance = float(fx["init_min_distance"])
+        st[i].last_distance = float(fx["init_last_distance"]); st[i].worsening = int(fx["init_worsening"])
+        st[i].crossed = int(fx["init_crossed"])
+    env.set_state(st)
+
+    k_reset = 0
+    worst = dict(obs=0.0, reward=0.0, distance=0.0, reset_obs=0.0)
+    for t in range(T):
+        rn = rn_all[k_reset] if fx["did_reset"][t] else rn0
+        env.set_noise(sn_all[t], rn)
+        obs, rew, term, trunc, info = env.step_torch(actions[t])
+        obs_h, rew_h = obs.cpu().numpy(), rew.cpu().numpy()
+        term_h, trunc_h = term.cpu().numpy(), trunc.cpu().numpy()
+        flags = info["flags"].cpu().numpy()
+        assert np.all(term_h == int(fx["terminated"][t])), (t, term_h, fx["terminated"][t])
+        assert np.all(trunc_h == int(fx["truncated"][t])), (t, trunc_h)
+        assert np.all((flags & 1) == int(fx["intercepted"][t])), (t, flags)
+        assert np.all(((flags >> 1) & 1) == int(fx["hit_target"][t])), (t, flags)
+        step_obs = info["terminal_observation"].cpu().numpy() if fx["did_reset"][t] else obs_h
+        worst["obs"] = max(worst["obs"], float(np.max(np.abs(step_obs - fx["obs"][t][None]))))
+        worst["reward"] = max(worst["reward"], float(np.max(_rel(rew_h, fx["reward"][t]))))
+        worst["distance"] = max(worst["distance"], float(np.max(_rel(info["distance"].cpu().numpy(), fx["distance"][t]))))
+        assert np.all(obs_h == obs_h[0:1]) and np.all(rew_h == rew_h[0]), "lanes with identical inputs diverged"
+        if fx["did_reset"][t]:
+            worst["reset_obs"] = max(worst["reset_obs"], float(np.max(np.abs(obs_h - fx["reset_obs"][k_reset][None]))))
+            k_reset += 1
+    assert worst["obs"] <= OBS_ATOL, worst
+    assert worst["reset_obs"] <= OBS_ATOL, worst
+    assert worst["reward"] <= 10 * RTOL, worst   # per-step reward = 100 x (difference of two ~4 km distances)
+    assert worst["distance"] <= RTOL, worst
+    # final state vs the recorded reference state
+    st = env.get_state()[0]
+    last = -1
+    for fld, key in (("int_pos", "st_int_pos"), ("int_vel", "st_int_vel"), ("int_quat", "st_int_quat"),
+                     ("mis_pos", "st_mis_pos"), ("mis_vel", "st_mis_vel"), ("wind", "st_wind")):
+        ref = fx[key][last] if not fx["did_reset"][T - 1] else fx["rst_" + fld][-1]
+        assert np.max(_rel(np.array(getattr(st, fld)[:]), ref)) <= 2 * RTOL, (fld, np.array(getattr(st, fld)[:]), ref)
+    env.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# (2) GPU vs oracle, seeded random batch, free-running, Philox draws exported to the oracle
+# ----------------------------------------------------------------------------------------------
+CASES = [
+    ("medium", "base", {}),
+    ("medium", "v2dr", {}),
+    ("hard", "v2", {"max_steps": 150}),
+    ("easy", "config", {"observation_mode": "body_frame", "max_steps": 120}),
+    ("medium", "v2", {"observation_mode": "los_frame", "proximity_fuze_enabled": True, "proximity_kill_radius": 60.0,
+                      "max_steps": 200}),
+    ("medium", "base", {"curriculum.precision_mode": True, "max_steps": 100}),
+]
+
+
+@pytest.mark.parametrize("scenario,physics,over", CASES)
+def test_gpu_matches_oracle_free_running(scenario, physics, over):
+    torch = _torch()
+    import oracle.oracle as orc
+    from hlynr_intercept_amd.config import resolve_config
+    from hlynr_intercept_amd.scenarios import scenario_config
+
+    rc = resolve_config(scenario_config(scenario, physics, over))
+    n, T = 1024, 260
+    env = _make_env(rc, n, seed=1234)
+    ora = orc.OracleVec(rc, n)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    sn, rn = env.fill_noise(for_reset=True)
+    # reset both from the same Philox draws
+    obs_g = env.reset_torch().cpu().numpy()
+    obs_o = ora.reset(rn.cpu().numpy().T.astype(np.float64))
+    assert np.max(np.abs(obs_g - obs_o)) <= OBS_ATOL
+    alive = np.ones(n, bool)     # envs whose discrete history still agrees
+    n_done_total = 0
+    worst = dict(obs=0.0, reward=0.0, distance=0.0)
+    for t in range(T):
+        a = (torch.rand((n, 6), generator=g) * 2 - 1)
+        if t % 3 == 0:   # mix in pursuit-like thrust so that intercepts happen
+            a[:, 2] = 0.9
+        sn, rn = env.fill_noise()
+        obs, rew, term, trunc, info = env.step_torch(a.to(env.device))
+        out = ora.step(a.numpy(), sn.cpu().numpy().T.astype(np.float64), rn.cpu().numpy().T.astype(np.float64))
+        term_h, trunc_h = term.cpu().numpy(), trunc.cpu().numpy()
+        same = (term_h == out["terminated"]) & (trunc_h == out["truncated"]) & \
+               ((info["flags"].cpu().numpy() & 1) == out["intercepted"])
+        alive &= same
+        done = (term_h | trunc_h).astype(bool)
+        n_done_total += int(done.sum())
+        obs_h = obs.cpu().numpy()
+        term_obs = info["terminal_observation"].cpu().numpy()
+        step_obs_g = np.where(done[:, None], term_obs, obs_h)
+        step_obs_o = np.where(done[:, None], ora.terminal_obs, out["obs"])
+        eo = np.max(np.abs(step_obs_g - step_obs_o), axis=1)
+        er = _rel(rew.cpu().numpy(), out["reward"])
+        ed = _rel(info["distance"].cpu().numpy(), out["distance"])
+        # an env whose observation jumps (a detection decided differently at a float32 boundary) is retired
+        alive &= eo <= 50 * OBS_ATOL
+        worst["obs"] = max(worst["obs"], float(eo[alive].max(initial=0.0)))
+        worst["reward"] = max(worst["reward"], float(er[alive].max(initial=0.0)))
+        worst["distance"] = max(worst["distance"], float(ed[alive].max(initial=0.0)))
+        # reset observations of finished envs
+        if done.any():
+            sel = done & alive
+            if sel.any():
+                assert np.max(np.abs(obs_h[sel] - out["obs"][sel])) <= OBS_ATOL
+    assert alive.mean() >= 0.995, f"{(~alive).sum()} of {n} envs diverged in their discrete history"
+    assert worst["obs"] <= OBS_ATOL, worst
+    assert worst["distance"] <= RTOL, worst
+    assert worst["reward"] <= 10 * RTOL, worst
+    # full state comparison at the end (alive envs)
+    st = env.get_state()
+    for name in ("int_pos", "int_vel", "int_quat", "mis_pos", "mis_vel", "wind"):
+        ref = ora.field(name)
+        mine = np.array([list(getattr(st[i], name)) for i in range(n)])
+        assert np.max(_rel(mine[alive], ref[alive])) <= 2 * RTOL, name
+    kx = np.array([list(st[i].kf_x) for i in range(n)])
+    assert np.max(_rel(kx[alive][:, :3], ora.field("kf_x")[alive][:, :3])) <= 5 * RTOL
+    P = np.array([list(st[i].kf_P) for i in range(n)])
+    Po = ora.field("kf_P").reshape(n, 6, 6)
+    Pref = np.stack([Po[:, 0, 0], Po[:, 0, 3], Po[:, 3, 0], Po[:, 3, 3]], axis=1)
+    assert np.max(np.abs(P[alive] - Pref[alive]) / np.maximum(1e-2, np.abs(Pref[alive]))) <= 1e-3
+    steps_g = np.array([st[i].steps for i in range(n)])
+    assert np.array_equal(steps_g[alive], ora.field("steps")[alive])
+    assert n_done_total > 0 or rc.max_steps > T, "case never exercised auto-reset"
+    env.close()
+
+
+def test_philox_path_equals_noise_buffer_path():
+    """The in-kernel Philox draws and the same draws fed through the noise buffers give identical bits."""
+    torch = _torch()
+    from hlynr_intercept_amd.config import resolve_config
+    from hlynr_intercept_amd.scenarios import scenario_config
+
+    rc = resolve_config(scenario_config("medium", "v2dr", {"max_steps": 40}))
+    n = 512
+    a_env, b_env = _make_env(rc, n, seed=99), _make_env(rc, n, seed=99)
+    sn, rn = b_env.fill_noise(for_reset=True)
+    b_env.set_noise(sn, rn)
+    oa, ob = a_env.reset_torch().clone(), b_env.reset_torch().clone()
+    assert torch.equal(oa, ob)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for t in range(100):
+        act = (torch.rand((n, 6), generator=g) * 2 - 1).to(a_env.device)
+        sn, rn = b_env.fill_noise()
+        b_env.set_noise(sn, rn)
+        ra = a_env.step_torch(act)
+        rb = b_env.step_torch(act)
+        for x, y in zip(ra[:4], rb[:4]):
+            assert torch.equal(x, y), t
+    a_env.close(); b_env.close()
+
+
+def test_sharding_is_concatenation():
+    """Env i's trajectory depends on (seed, global env id), not on which shard / GPU holds it."""
+    torch = _torch()
+    from hlynr_intercept_amd.config import resolve_config
+    from hlynr_intercept_amd.scenarios import scenario_config
+
+    rc = resolve_config(scenario_config("medium", "base", {"max_steps": 50}))
+    n = 640
+    whole = _make_env(rc, n, seed=5)
+    lo, hi = _make_env(rc, 256, seed=5, offset=0), _make_env(rc, n - 256, seed=5, offset=256)
+    o = whole.reset_torch().clone()
+    assert torch.equal(o, torch.cat([lo.reset_torch(), hi.reset_torch()]))
+    g = torch.Generator(device="cpu").manual_seed(11)
+    for t in range(120):
+        act = (torch.rand((n, 6), generator=g) * 2 - 1).to(whole.device)
+        rw = whole.step_torch(act)
+        rl, rh = lo.step_torch(act[:256].contiguous()), hi.step_torch(act[256:].contiguous())
+        for k in range(4):
+            assert torch.equal(rw[k], torch.cat([rl[k], rh[k]])), (t, k)
+    whole.close(); lo.close(); hi.close()
