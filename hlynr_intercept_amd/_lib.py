@@ -23,20 +23,21 @@ F_PROX_FUZE, F_GROUND, F_SPHERICAL, F_TOWARD_MISSILE, F_OBS_BODY, F_OBS_LOS, F_U
 
 class HlxConfig(C.Structure):
     _fields_ = [
-        ("flags", u32), ("max_steps", i32), ("dt", f32), ("max_range", f32), ("max_velocity", f32),
-        ("target_pos", f32 * 3), ("mis_pos_lo", f32 * 3), ("mis_pos_hi", f32 * 3),
-        ("mis_radius", f32 * 2), ("mis_azimuth_deg", f32 * 2), ("mis_elevation_deg", f32 * 2), ("mis_speed", f32 * 2),
-        ("int_pos_lo", f32 * 3), ("int_pos_hi", f32 * 3), ("int_vel_lo", f32 * 3), ("int_vel_hi", f32 * 3),
-        ("int_speed", f32 * 2),
-        ("subsonic_mach", f32), ("supersonic_mach", f32), ("transonic_peak_multiplier", f32),
-        ("supersonic_multiplier", f32),
-        ("base_wind", f32 * 3), ("wind_variability", f32), ("boundary_layer_height", f32),
-        ("turbulence_intensity", f32), ("gust_scale", f32), ("thrust_tau", f32),
-        ("dr_variations", f32 * 13), ("proximity_kill_radius", f32),
-        ("radar_quality", f32), ("radar_range", f32), ("radar_beam_width", f32), ("onboard_delay", i32),
-        ("ground_pos", f32 * 3), ("ground_max_range", f32), ("ground_min_elev", f32), ("ground_max_elev", f32),
-        ("ground_range_accuracy", f32), ("ground_velocity_accuracy", f32), ("ground_base_quality", f32),
-        ("max_datalink_range", f32), ("datalink_packet_loss", f32), ("weather_factor", f32), ("ground_delay", i32),
+        ("flags", u32), ("max_steps", i32), ("onboard_delay", i32), ("ground_delay", i32),
+        ("dt", f64), ("max_range", f64), ("max_velocity", f64),
+        ("target_pos", f64 * 3), ("mis_pos_lo", f64 * 3), ("mis_pos_hi", f64 * 3),
+        ("mis_radius", f64 * 2), ("mis_azimuth_deg", f64 * 2), ("mis_elevation_deg", f64 * 2), ("mis_speed", f64 * 2),
+        ("int_pos_lo", f64 * 3), ("int_pos_hi", f64 * 3), ("int_vel_lo", f64 * 3), ("int_vel_hi", f64 * 3),
+        ("int_speed", f64 * 2),
+        ("subsonic_mach", f64), ("supersonic_mach", f64), ("transonic_peak_multiplier", f64),
+        ("supersonic_multiplier", f64),
+        ("base_wind", f64 * 3), ("wind_variability", f64), ("boundary_layer_height", f64),
+        ("turbulence_intensity", f64), ("gust_scale", f64), ("thrust_tau", f64),
+        ("dr_variations", f64 * 13), ("proximity_kill_radius", f64),
+        ("radar_quality", f64), ("radar_range", f64), ("radar_beam_width", f64),
+        ("ground_pos", f64 * 3), ("ground_max_range", f64), ("ground_min_elev", f64), ("ground_max_elev", f64),
+        ("ground_range_accuracy", f64), ("ground_velocity_accuracy", f64), ("ground_base_quality", f64),
+        ("max_datalink_range", f64), ("datalink_packet_loss", f64), ("weather_factor", f64),
         ("initial_radius", f64), ("final_radius", f64), ("curriculum_steps", f64),
         ("rc_beam", f64 * 4), ("rc_onboard", f64 * 4), ("rc_ground", f64 * 4), ("rc_noise", f64 * 4),
     ]
@@ -50,10 +51,10 @@ class HlxInfoSoa(C.Structure):
 class HlxEnvState(C.Structure):
     _fields_ = [
         ("int_pos", f32 * 3), ("int_vel", f32 * 3), ("int_quat", f32 * 4), ("fuel", f32),
-        ("thrust_actual", f32 * 3), ("mis_pos", f32 * 3), ("mis_vel", f32 * 3), ("wind", f32 * 3),
+        ("thrust_actual", f32 * 3), ("mis_pos", f32 * 3), ("mis_vel", f32 * 3),
         ("prev_distance", f32), ("min_distance", f32), ("last_distance", f32),
-        ("steps", i32), ("worsening", i32), ("crossed", i32), ("kf_init", i32),
-        ("kf_x", f32 * 6), ("kf_P", f32 * 4),
+        ("steps", i32), ("worsening", i32), ("crossed", i32), ("kf_init", i32), ("kf_x_is64", i32), ("pad0", i32),
+        ("wind", f64 * 3), ("kf_x", f64 * 6), ("kf_P", f32 * 4),
         ("on_delay", i32), ("on_len", i32), ("on_ring", (f32 * 4) * RING_CAP),
         ("g_len", i32), ("g_ring", (f32 * 8) * RING_CAP),
         ("T0", f32), ("base_cd", f32), ("transonic_peak", f32), ("ep_return", f32),

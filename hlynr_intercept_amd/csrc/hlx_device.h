@@ -1,11 +1,25 @@
 // hlx_device.h -- device-side building blocks of the fused intercept-environment step (gfx950).
 //
-// One lane = one environment.  Everything here is float32 and register resident; the only
-// LDS use is the [64][26] observation tile that turns per-lane rows into coalesced 16-byte
-// stores (see hlx_kernels.hip).  No MFMA: the path is per-environment physics, not a contraction.
+// One lane = one environment, everything register resident.  No MFMA: the path is per-environment
+// physics, not a contraction.
 //
-// Citations are to the reference (RomanSlack/Hlynr_Intercept, rl_system/...), whose arithmetic
-// these functions restate; oracle/hlx_oracle.c is the CPU restatement they are tested against.
+// ARITHMETIC DISCIPLINE (this translation unit is compiled with -ffp-contract=off):
+// the reference (RomanSlack/Hlynr_Intercept, numpy >= 2) evaluates the step in a fixed mix of
+// float32 and float64.  Per-step rewards are differences of two ~km distances, so a 1-ulp
+// difference in a position shows up as a 1e-4 relative error in the reward; to stay inside the
+// 1e-5 bar the integrator chain is restated operation by operation:
+//   * float32 where the reference is float32: plain IEEE +,-,*,/ and sqrt, NO fused multiply-add;
+//   * np.dot / np.linalg.norm of float32 3-vectors = float32 products accumulated in float64 and
+//     rounded once (OpenBLAS sdot) -> sdot3()/snorm3();
+//   * float64 where the reference is float64 (simple-wind state, missile acceleration, Kalman
+//     state after a ground-radar measurement): MI355X runs fp64 vector math at half the fp32 rate,
+//     so this costs a few dozen instructions, not a redesign;
+//   * x / c for a constant c: (float)((double)x * (1.0 / c)) -- equals the correctly rounded
+//     float32 quotient except with probability ~1e-8 per operation, at a third of the cost of an
+//     IEEE float32 division.
+// Pure outputs (the 26-D observation formulas) use ordinary fast float32.
+// oracle/hlx_oracle.c is the CPU restatement these functions are tested against; citations are to
+// the reference's rl_system/ files.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -17,17 +31,35 @@ namespace hlx {
 struct V3 {
     float x, y, z;
 };
+struct D3 {
+    double x, y, z;
+};
 DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
 DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 DEV V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
-DEV V3 operator*(float s, V3 a) { return V3{a.x * s, a.y * s, a.z * s}; }
+DEV V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
 DEV V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
-DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-DEV float norm(V3 a) { return sqrtf(dot(a, a)); }
+DEV D3 d3(double x, double y, double z) { return D3{x, y, z}; }
+DEV D3 to_d3(V3 a) { return D3{(double)a.x, (double)a.y, (double)a.z}; }
+DEV V3 to_v3(D3 a) { return V3{(float)a.x, (float)a.y, (float)a.z}; }
+DEV D3 operator+(D3 a, D3 b) { return D3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+DEV D3 operator-(D3 a, D3 b) { return D3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+DEV D3 operator*(D3 a, double s) { return D3{a.x * s, a.y * s, a.z * s}; }
+DEV double ddot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DEV double dnorm(D3 a) { return sqrt(ddot(a, a)); }
+
+// numpy float32 dot / norm (OpenBLAS sdot): float32 products, float64 accumulation, one rounding
+DEV float sdot3(V3 a, V3 b) { return (float)(((double)(a.x * b.x) + (double)(a.y * b.y)) + (double)(a.z * b.z)); }
+DEV float snorm3(V3 a) { return sqrtf(sdot3(a, a)); }
 DEV V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
-DEV V3 clamp3(V3 a, float lo, float hi) { return V3{clampf(a.x, lo, hi), clampf(a.y, lo, hi), clampf(a.z, lo, hi)}; }
+// x / c with c a constant whose float64 reciprocal is `inv`
+DEV float divc(float x, double inv) { return (float)((double)x * inv); }
+DEV V3 divc(V3 a, double inv) { return V3{divc(a.x, inv), divc(a.y, inv), divc(a.z, inv)}; }
+// fast (non-mirrored) helpers for pure outputs
+DEV float fdot(V3 a, V3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+DEV float fnorm(V3 a) { return __builtin_sqrtf(fdot(a, a)); }
 
 // ---------------------------------------------------------------------------------------------
 // Counter-based RNG: Philox4x32-10 keyed by the env-set seed; counter = (global env id, vec-step,
@@ -45,8 +77,8 @@ DEV uint4 philox4x32_10(uint4 c, uint2 k) {
     }
     return c;
 }
-DEV float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }          // [0,1)
-DEV float u01_open(uint32_t x) { return (float)((x >> 8) + 1u) * 5.9604644775390625e-08f; } // (0,1]
+DEV float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }             // [0,1)
+DEV float u01_open(uint32_t x) { return (float)((x >> 8) + 1u) * 5.9604644775390625e-08f; }  // (0,1]
 // Box-Muller on two 32-bit words; v_sin/v_cos take revolutions, so 2*pi*u needs no range reduction.
 DEV void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
     float r = sqrtf(-2.0f * __logf(u01_open(a)));
@@ -71,9 +103,8 @@ enum : uint32_t {
     RS_RESET_U0 = 8, RS_RESET_U1 = 9, RS_RESET_U2 = 10, RS_RESET_OBS_U = 11, RS_RESET_GPOS = 12, RS_RESET_GVEL = 13,
     RS_DR0 = 14, RS_DR1 = 15, RS_DR2 = 16, RS_DR3 = 17
 };
-
 // physics_models.py:382-384 gust direction N(0,1)^3 and magnitude Exp(1)
-DEV void gust_draws(const Rng& rng, struct V3& g, float& e) {
+DEV void gust_draws(const Rng& rng, V3& g, float& e) {
     uint4 x = rng.raw(RS_GUST), y = rng.raw(RS_GUST + 1);
     float w_;
     box_muller(x.x, x.y, g.x, g.y);
@@ -82,7 +113,7 @@ DEV void gust_draws(const Rng& rng, struct V3& g, float& e) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// physics_models.py:154-177  ISA atmosphere -> density, speed of sound
+// physics_models.py:154-177  ISA atmosphere (float32 altitude) -> density, speed of sound
 // ---------------------------------------------------------------------------------------------
 DEV void atmosphere(float alt, float T0, float& rho, float& sos) {
     constexpr float R = 287.05f, G = 9.80665f, L = 0.0065f;
@@ -94,7 +125,7 @@ DEV void atmosphere(float alt, float T0, float& rho, float& sos) {
         P = 101325.0f * powf(T / T0, EXPO);       // :95-100
     } else if (alt <= 20000.0f) {                 // :72-74,102-108 (not reachable in shipped scenarios)
         T = 216.65f;
-        P = 22632.0f * expf(-G * (alt - 11000.0f) / (R * 216.65f));
+        P = 22632.0f * expf((-G * (alt - 11000.0f)) / (float)(287.05 * 216.65));
     } else {                                      // :76-78,110-113
         float ex = alt - 20000.0f;
         T = 216.65f * expf(-ex / 10000.0f);
@@ -106,34 +137,41 @@ DEV void atmosphere(float alt, float T0, float& rho, float& sos) {
 }
 
 struct DragParams {
-    float subsonic, supersonic, peak, super_mult, base_cd;
+    float subsonic, supersonic, mach_span, peak, base_cd, cd_super;   // cd_super = F(base_cd * supersonic_multiplier)
 };
-// physics_models.py:236-264 drag force / mass -> acceleration (area, extra scale folded in by caller)
-DEV V3 mach_drag_accel(V3 v, float rho, float sos, float area_scale, float inv_mass, const DragParams& p) {
-    float vm = norm(v);
+// physics_models.py:236-264  drag force vector (float32 velocity); `area` = reference_area
+DEV V3 mach_drag_force(V3 v, float rho, float sos, float area, const DragParams& p) {
+    float vm = snorm3(v);
     if (vm < 1e-6f) return v3(0.f, 0.f, 0.f);
-    float mach = vm / sos;                        // :233-234
+    float mach = vm / sos;                                                  // :233-234
     float cd;
-    if (mach < p.subsonic) cd = p.base_cd;        // :207-209
+    if (mach < p.subsonic) cd = p.base_cd;                                  // :207-209
     else if (mach < p.supersonic) {
-        float frac = (mach - p.subsonic) / (p.supersonic - p.subsonic);   // :213-214
-        cd = p.base_cd * (1.0f + (p.peak - 1.0f) * frac);                 // :215-216
-    } else cd = p.base_cd * p.super_mult;         // :220
-    float mag = 0.5f * rho * (vm * vm) * cd * area_scale;                 // :258
-    float k = -(mag / vm) * inv_mass;             // :262-264
-    return v * k;
+        float frac = (mach - p.subsonic) / p.mach_span;                     // :213-214
+        cd = p.base_cd * (1.0f + (p.peak - 1.0f) * frac);                   // :215-216
+    } else cd = p.cd_super;                                                 // :220 (python-float product)
+    float a = (((0.5f * rho) * (vm * vm)) * cd) * area;                     // :258
+    return V3{(-v.x / vm) * a, (-v.y / vm) * a, (-v.z / vm) * a};           // :262-264
 }
-// environment.py:920-921, 1099-1100
-DEV V3 simple_drag_accel(V3 v, float rho, float inv_mass) {
-    float k = (-0.5f * 0.3f) * rho * norm(v) * inv_mass;
-    return v * k;
+// the same with a float64 air-relative velocity (Mach model on, simple float64 wind): generic kernel only
+DEV D3 mach_drag_force64(D3 v, float rho, float sos, double area, const DragParams& p) {
+    double vm = dnorm(v);
+    if (vm < 1e-6) return d3(0., 0., 0.);
+    double mach = vm / (double)sos;
+    double cd;
+    if (mach < (double)p.subsonic) cd = p.base_cd;
+    else if (mach < (double)p.supersonic)
+        cd = (double)p.base_cd * (1.0 + ((double)p.peak - 1.0) * ((mach - (double)p.subsonic) / ((double)p.supersonic - (double)p.subsonic)));
+    else cd = (double)p.cd_super;
+    double a = ((((double)(0.5f * rho)) * (vm * vm)) * cd) * area;
+    return D3{(-v.x / vm) * a, (-v.y / vm) * a, (-v.z / vm) * a};
 }
-// environment.py:927-930 / 1111-1113 nan_to_num(nan=0, +-inf=+-lim) applied when any component is non-finite
-DEV V3 nan_guard(V3 a, float lim) {
+// environment.py:927-930 / 1111-1113 nan_to_num(nan=0, +-inf=+-lim), applied when any component is non-finite
+DEV D3 nan_guard(D3 a, double lim) {
     bool ok = isfinite(a.x) && isfinite(a.y) && isfinite(a.z);
     if (ok) return a;
-    auto fix = [lim](float x) { return isnan(x) ? 0.0f : (isinf(x) ? (x > 0.f ? lim : -lim) : x); };
-    return V3{fix(a.x), fix(a.y), fix(a.z)};
+    auto fix = [lim](double x) { return isnan(x) ? 0.0 : (isinf(x) ? (x > 0. ? lim : -lim) : x); };
+    return D3{fix(a.x), fix(a.y), fix(a.z)};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -144,25 +182,25 @@ struct Quat {
 };
 DEV V3 forward_vec(Quat q) {   // core.py:1143-1152
     V3 f = v3(2.f * (q.x * q.z + q.w * q.y), 2.f * (q.y * q.z - q.w * q.x), 1.f - 2.f * (q.x * q.x + q.y * q.y));
-    return f * (1.0f / (norm(f) + 1e-6f));
+    return f / (snorm3(f) + 1e-6f);
 }
 DEV V3 right_vec(Quat q) {     // core.py:1155-1164
     V3 f = v3(1.f - 2.f * (q.y * q.y + q.z * q.z), 2.f * (q.x * q.y + q.w * q.z), 2.f * (q.x * q.z - q.w * q.y));
-    return f * (1.0f / (norm(f) + 1e-6f));
+    return f * (1.0f / (fnorm(f) + 1e-6f));
 }
 DEV V3 up_vec(Quat q) {        // core.py:1167-1176
     V3 f = v3(2.f * (q.x * q.y - q.w * q.z), 1.f - 2.f * (q.x * q.x + q.z * q.z), 2.f * (q.y * q.z + q.w * q.x));
-    return f * (1.0f / (norm(f) + 1e-6f));
+    return f * (1.0f / (fnorm(f) + 1e-6f));
 }
-DEV Quat quat_mul(Quat a, Quat b) {  // environment.py:1322-1331
-    return Quat{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
-                a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+DEV Quat quat_mul(Quat a, Quat b) {  // environment.py:1322-1331 (left-to-right float32 sums)
+    return Quat{((a.w * b.w - a.x * b.x) - a.y * b.y) - a.z * b.z, ((a.w * b.x + a.x * b.w) + a.y * b.z) - a.z * b.y,
+                ((a.w * b.y - a.x * b.z) + a.y * b.w) + a.z * b.x, ((a.w * b.z + a.x * b.y) - a.y * b.x) + a.z * b.w};
 }
 // LOS orthonormal basis: environment.py:1006-1020 == core.py:824-834,939-945
 DEV void los_basis(V3 lu, V3& h, V3& v) {
     V3 right = cross(lu, v3(0.f, 0.f, 1.f));
-    float n = norm(right);
-    h = (n > 1e-6f) ? right * (1.0f / n) : v3(1.f, 0.f, 0.f);
+    float n = snorm3(right);
+    h = (n > 1e-6f) ? right / n : v3(1.f, 0.f, 0.f);
     v = cross(lu, h);
 }
 

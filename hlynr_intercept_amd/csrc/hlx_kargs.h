@@ -15,42 +15,54 @@ constexpr uint32_t KF_CODEGEN_MASK = HLX_F_ATMOSPHERE | HLX_F_MACH_DRAG | HLX_F_
                                      HLX_F_PROX_FUZE | HLX_F_GROUND | HLX_F_SPHERICAL | HLX_F_TOWARD_MISSILE |
                                      HLX_F_OBS_BODY | HLX_F_OBS_LOS;
 
-// State arena: float4 groups, struct-of-arrays: arena[group][env]
+// State arena: 16-byte groups, struct-of-arrays: arena[group][env].  Every load/store of a group is
+// one 16-byte-per-lane, 1-KiB-per-wave coalesced access.
 enum : int {
-    G_IPOS = 0,  // interceptor position xyz, fuel
-    G_IVEL,      // interceptor velocity xyz, prev_distance
-    G_QUAT,      // orientation w x y z
-    G_MPOS,      // missile position xyz, episode min distance
-    G_MVEL,      // missile velocity xyz, last_distance (smart early termination)
-    G_WIND,      // wind xyz, packed {steps:13, worsening:13, crossed:1, kf_init:1, onboard_delay:4}
-    G_KFP,       // Kalman position estimate xyz, p_pp
-    G_KFV,       // Kalman velocity estimate xyz, p_pv
-    G_MISC,      // p_vp, p_vv, episode return, sea-level temperature T0
-    G_THRUST,    // actual thrust xyz (thrust lag), pad
-    G_DR,        // base_cd, transonic peak multiplier (domain randomisation), pad, pad
+    G_IPOS = 0,  // float4: interceptor position xyz, fuel
+    G_IVEL,      // float4: interceptor velocity xyz, prev_distance
+    G_QUAT,      // float4: orientation w x y z
+    G_MPOS,      // float4: missile position xyz, episode min distance
+    G_MVEL,      // float4: missile velocity xyz, last_distance (smart early termination)
+    G_W0,        // double2: wind x, y        (float64 state in the reference's simple-wind mode)
+    G_W1,        // {double wind z, uint32 packed, float episode return}
+                 //   packed = steps:13 | worsening:12 | crossed:1 | kf_init:1 | kf_x_is64:1 | onboard_delay:4
+    G_KF0,       // double2: Kalman position estimate x, y
+    G_KF1,       // double2: Kalman position z, velocity x
+    G_KF2,       // double2: Kalman velocity y, z
+    G_KFP,       // float4: covariance block p_pp, p_pv, p_vp, p_vv
+    G_THRUST,    // float4: actual thrust xyz (thrust lag), pad               [thrust lag only]
+    G_MISC,      // float4: T0, base_cd, transonic peak multiplier, pad       [domain randomisation only]
     N_GROUPS
 };
+constexpr int GROUND_RING_WORDS16 = 2;  // float4 {rel_pos xyz, quality}, float4 {rel_vel xyz, measurement-is-float64 flag}
 
 struct KCfg {
     uint32_t flags;
-    int32_t max_steps;
-    float dt, max_range, max_velocity;
+    int32_t max_steps, g_delay, o_delay, o_cap;
+    float dt;                 // F(dt)
+    double dt64, inv_dtf;     // dt ; 1 / (double)F(dt)
+    float max_range, max_velocity;
     float target[3];
-    float mis_lo[3], mis_span[3], mis_radius[2], mis_az[2], mis_el[2], mis_speed[2];
-    float int_lo[3], int_span[3], ivel_lo[3], ivel_span[3], int_speed[2];
-    float subsonic, supersonic, peak, super_mult;
-    float base_wind[3], wind_var, bl_height, bl_prof, turb, turb_lp, gust_scale, thrust_tau;
-    float dr_var[5];
+    double mis_lo[3], mis_span[3], mis_radius[2], mis_az[2], mis_el[2], mis_speed[2];
+    double int_lo[3], int_span[3], ivel_lo[3], ivel_span[3], int_speed[2];
+    float subsonic, supersonic, mach_span, peak, cd_super;
+    double super_mult;
+    float base_wind[3];
+    double wind_var;
+    float bl_height, bl_prof, ti_low, ti_mid, ti_high;
+    double turb_lp, gust_scale, inv_tau;
+    double dr_var[5];
     float kill_radius, radar_quality, radar_range;
-    float ground_pos[3], g_max_range, g_min_elev, g_max_elev, g_range_acc, g_vel_acc, g_base_q;
-    float max_datalink, packet_loss, weather;
-    int32_t g_delay, o_delay, o_cap;
-    float q11, q12, q22;  // Kalman process noise (core.py:34-42, q = 5^2)
+    double radar_quality64;
+    float ground_pos[3], g_max_range, g_base_q, max_datalink, weather;
+    double g_min_elev, g_max_elev, g_range_acc, g_vel_acc, packet_loss;
+    float q11, q12, q22;      // Kalman process noise (core.py:34-42, q = 5^2)
 };
 
 struct KArgs {
     KCfg c;
-    float radius, half_beam, on_rel, g_rel;  // curriculum scalars in force for this launch
+    float radius, on_rel, g_rel;  // curriculum scalars in force for this launch
+    double half_beam;
     float4* arena;
     float4* gring;  // [g_delay+1][2][N]
     float4* oring;  // [o_cap][N]

@@ -1,4 +1,5 @@
 // hlx_kernels.hip -- the fused intercept-environment step for MI355X (gfx950 / CDNA4).
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off   (see hlx_device.h, ARITHMETIC DISCIPLINE)
 //
 // One kernel launch = one `VecEnv.step`: safety clamp -> interceptor 6-DOF integrator -> missile
 // -> wind -> intercept/termination -> reward -> radar/ground-radar/datalink/fusion -> Kalman filter
@@ -10,14 +11,14 @@
 //     needed between waves, and N/64 workgroups spread evenly over the 256 CUs / 8 XCDs.  The
 //     env -> workgroup mapping is the same every launch, so the slice of the arena a workgroup
 //     touches stays in the L2 of the XCD it is dispatched to (round-robin by workgroup id).
-//   * state arena = struct-of-arrays of float4 "groups": every state load/store is a 16-byte-per-
-//     lane, 1 KiB-per-wave fully coalesced access (9 groups base physics, 11 with physics v2).
+//   * state arena = struct-of-arrays of 16-byte groups: every state load/store is a 16-byte-per-
+//     lane, 1 KiB-per-wave fully coalesced access (11 groups base physics, 13 with physics v2 + DR).
 //   * delay rings are planes indexed by the GLOBAL vec-step clock, so ring traffic is coalesced
 //     too although every environment is at a different step of its own episode.
 //   * the 26-float observation row of each lane goes through a [64][26] LDS tile and leaves as
 //     16-byte coalesced stores of the row-major [N][26] array the policy consumes.
 //   * finished environments: wave ballot + popcount + one atomic per wave compacts their indices.
-//   * no MFMA: per-environment physics has no dense contraction (HBM/latency bound).
+//   * no MFMA: per-environment physics has no dense contraction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -30,6 +31,8 @@ using namespace hlx;
 namespace {
 
 #define HAS(f) ((FL & (uint32_t)(f)) != 0u)
+
+DEV double rr(double x, bool is64) { return is64 ? x : (double)(float)x; }
 
 template <uint32_t SPEC, int MODE /*0 = step, 1 = reset-only*/>
 __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
@@ -47,27 +50,31 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
     if (live) {
         const size_t N = (size_t)n;
         float4* A = a.arena + i;
+        double2* AD = reinterpret_cast<double2*>(a.arena) + i;
         // ------------------------------------------------------------------ load state
         float4 g_ipos = A[G_IPOS * N], g_ivel = A[G_IVEL * N], g_quat = A[G_QUAT * N], g_mpos = A[G_MPOS * N];
-        float4 g_mvel = A[G_MVEL * N], g_wind = A[G_WIND * N], g_kfp = A[G_KFP * N], g_kfv = A[G_KFV * N];
-        float4 g_misc = A[G_MISC * N];
-        float4 g_thr = make_float4(0.f, 0.f, 0.f, 0.f), g_dr = make_float4(0.3f, c.peak, 0.f, 0.f);
+        float4 g_mvel = A[G_MVEL * N], g_w1 = A[G_W1 * N], g_kfp = A[G_KFP * N];
+        double2 g_w0 = AD[G_W0 * N], g_kf0 = AD[G_KF0 * N], g_kf1 = AD[G_KF1 * N], g_kf2 = AD[G_KF2 * N];
+        float4 g_thr = make_float4(0.f, 0.f, 0.f, 0.f), g_misc = make_float4(288.15f, 0.3f, c.peak, 0.f);
         if (HAS(HLX_F_THRUST_LAG)) g_thr = A[G_THRUST * N];
-        if (HAS(HLX_F_DOMAIN_RAND)) g_dr = A[G_DR * N];
+        if (HAS(HLX_F_DOMAIN_RAND)) g_misc = A[G_MISC * N];
 
         V3 ipos = v3(g_ipos.x, g_ipos.y, g_ipos.z), ivel = v3(g_ivel.x, g_ivel.y, g_ivel.z);
         Quat q = Quat{g_quat.x, g_quat.y, g_quat.z, g_quat.w};
         V3 mpos = v3(g_mpos.x, g_mpos.y, g_mpos.z), mvel = v3(g_mvel.x, g_mvel.y, g_mvel.z);
-        V3 wind = v3(g_wind.x, g_wind.y, g_wind.z);
+        D3 wind = d3(g_w0.x, g_w0.y, __hiloint2double(__float_as_int(g_w1.y), __float_as_int(g_w1.x)));
         float fuel = g_ipos.w, prev_distance = g_ivel.w, min_distance = g_mpos.w, last_distance = g_mvel.w;
-        uint32_t packed = __float_as_uint(g_wind.w);
-        int steps = (int)(packed & 0x1FFFu), worsening = (int)((packed >> 13) & 0x1FFFu);
-        bool crossed = (packed >> 26) & 1u, kf_init = (packed >> 27) & 1u;
+        uint32_t packed = __float_as_uint(g_w1.z);
+        float ep_return = g_w1.w;
+        int steps = (int)(packed & 0x1FFFu), worsening = (int)((packed >> 13) & 0xFFFu);
+        bool crossed = (packed >> 25) & 1u, kf_init = (packed >> 26) & 1u, kf_x64 = (packed >> 27) & 1u;
         int on_delay = (int)(packed >> 28);
-        V3 kxp = v3(g_kfp.x, g_kfp.y, g_kfp.z), kxv = v3(g_kfv.x, g_kfv.y, g_kfv.z);
-        float p_pp = g_kfp.w, p_pv = g_kfv.w, p_vp = g_misc.x, p_vv = g_misc.y, ep_return = g_misc.z, T0 = g_misc.w;
+        D3 kxp = d3(g_kf0.x, g_kf0.y, g_kf1.x), kxv = d3(g_kf1.y, g_kf2.x, g_kf2.y);
+        float p_pp = g_kfp.x, p_pv = g_kfp.y, p_vp = g_kfp.z, p_vv = g_kfp.w;
         V3 thrust_act = v3(g_thr.x, g_thr.y, g_thr.z);
-        DragParams dp{c.subsonic, c.supersonic, g_dr.y, c.super_mult, g_dr.x};
+        float T0 = g_misc.x;
+        DragParams dp{c.subsonic, c.supersonic, c.mach_span, g_misc.z, g_misc.y, c.cd_super};
+        if (HAS(HLX_F_DOMAIN_RAND)) dp.cd_super = (float)((double)dp.base_cd * c.super_mult);
 
         const bool noise_buf = a.step_noise != nullptr;
         const unsigned long long gid = (unsigned long long)(a.env_offset + i);
@@ -88,108 +95,157 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
             steps += 1;                                                             // :607
             if (HAS(HLX_F_OBS_LOS)) {                                               // :618-620, :965-1063
                 V3 rel0 = mpos - ipos;
-                float rg = norm(rel0);
-                V3 lu = (rg > 1e-6f) ? rel0 * (1.0f / rg) : v3(1.f, 0.f, 0.f);
+                float rg = snorm3(rel0);
+                V3 lu = (rg > 1e-6f) ? rel0 / rg : v3(1.f, 0.f, 0.f);
                 V3 h, v;
                 los_basis(lu, h, v);
-                at = lu * at.x + h * at.y + v * at.z;
+                at = (lu * at.x + h * at.y) + v * at.z;                             // :1052-1056
             }
             if (fuel <= 0.f) { at = at * 0.f; clamped = true; }                      // core.py:1080-1083
-            float am = norm(at);
+            float am = snorm3(at);
             if (am > 50.f) { at = at * (50.f / am); clamped = true; }                // core.py:1086-1090
-            float gm = norm(aw);
+            float gm = snorm3(aw);
             if (gm > 5.f) { aw = aw * (5.f / gm); clamped = true; }                  // core.py:1094-1098
+
+            // Is the reference's wind a float64 array at this point?  Simple wind: float32 copy of
+            // base_wind after reset, float64 from the first update on (environment.py:542,1127-1129).
+            const bool simple_wind = !HAS(HLX_F_ENH_WIND) && c.wind_var > 0.0;
+            const bool w64 = simple_wind && steps > 1;
 
             // -------------------------------------------------------------- interceptor (environment.py:861-956)
             V3 thr = at * 10000.f, ang = aw * 20.f;                                 // :870-871
             if (HAS(HLX_F_THRUST_LAG)) {                                            // :874-878
                 V3 err = thr - thrust_act;
-                thrust_act = thrust_act + (err * c.dt) * (1.0f / c.thrust_tau);
+                thrust_act = thrust_act + divc(err * c.dt, c.inv_tau);
                 thr = thrust_act;
             }
-            float fc = norm(thr) / 500.f * 0.1f * c.dt;                             // :883-884
-            fuel -= fc;
+            float fc = (divc(snorm3(thr), 1.0 / 500.0) * 0.1f) * c.dt;              // :883-884
+            fuel = fuel - fc;
             if (fuel <= 0.f) { fuel = 0.f; thr = v3(0.f, 0.f, 0.f); thrust_act = thr; } // :888-892
+            const V3 tacc = divc(thr, 1.0 / 500.0);                                 // :896
             float rho = 1.225f, sos = 343.f;
             if (HAS(HLX_F_ATMOSPHERE)) atmosphere(fmaxf(ipos.z, 0.f), T0, rho, sos); // :899-906
-            const V3 grav = v3(0.f, 0.f, -9.81f);
-            {
-                V3 va = ivel - wind;                                                // :910
+            const float GRAV = -9.81f;
+            if (w64) {                                                              // float64 air-relative velocity
+                D3 va = to_d3(ivel) - wind;                                         // :910
+                D3 dacc;
+                if (HAS(HLX_F_MACH_DRAG) && dnorm(va) > 1e-6) dacc = mach_drag_force64(va, rho, sos, 1.0, dp) * (1.0 / 500.0);
+                else {                                                              // :920-921
+                    double c1 = HAS(HLX_F_ATMOSPHERE) ? (double)(-0.15f * rho) : (-0.5 * 0.3 * 1.225);
+                    double c2 = c1 * dnorm(va);
+                    dacc = d3((c2 * va.x) / 500.0, (c2 * va.y) / 500.0, (c2 * va.z) / 500.0);
+                }
+                D3 acc = d3((double)tacc.x + dacc.x, (double)tacc.y + dacc.y, ((double)tacc.z + dacc.z) + (double)GRAV); // :924
+                if (HAS(HLX_F_VALIDATION)) acc = nan_guard(acc, 50.0);
+                ivel = v3((float)((double)ivel.x + acc.x * c.dt64), (float)((double)ivel.y + acc.y * c.dt64),
+                          (float)((double)ivel.z + acc.z * c.dt64));                // :933
+            } else {
+                V3 va = ivel - to_v3(wind);
                 V3 dacc;
-                if (HAS(HLX_F_MACH_DRAG) && norm(va) > 1e-6f) dacc = mach_drag_accel(va, rho, sos, 1.0f, 1.0f / 500.f, dp);
-                else dacc = simple_drag_accel(va, rho, 1.0f / 500.f);               // :912-921
-                V3 acc = thr * (1.0f / 500.f) + dacc + grav;                        // :896,:924
-                if (HAS(HLX_F_VALIDATION)) acc = nan_guard(acc, 50.f);
-                ivel = ivel + acc * c.dt;                                           // :933
-                ipos = ipos + ivel * c.dt;                                          // :934
+                if (HAS(HLX_F_MACH_DRAG) && snorm3(va) > 1e-6f) dacc = divc(mach_drag_force(va, rho, sos, 1.0f, dp), 1.0 / 500.0);
+                else {
+                    float c1 = HAS(HLX_F_ATMOSPHERE) ? (-0.15f * rho) : (float)(-0.5 * 0.3 * 1.225);
+                    float c2 = c1 * snorm3(va);
+                    dacc = divc(va * c2, 1.0 / 500.0);
+                }
+                V3 acc = v3(tacc.x + dacc.x, tacc.y + dacc.y, (tacc.z + dacc.z) + GRAV);
+                if (HAS(HLX_F_VALIDATION)) acc = to_v3(nan_guard(to_d3(acc), 50.0));
+                ivel = ivel + acc * c.dt;
             }
+            ipos = ipos + ivel * c.dt;                                              // :934
             {
-                float wn = norm(ang);                                               // :940-956
+                float wn = snorm3(ang);                                             // :940-956
                 float angle = wn * c.dt;
                 if (angle > 1e-6f) {
-                    float sh, ch;
-                    sincosf(0.5f * angle, &sh, &ch);
-                    float k = sh / wn;
-                    Quat r = quat_mul(Quat{ch, ang.x * k, ang.y * k, ang.z * k}, q);
-                    float inv = 1.0f / sqrtf(r.w * r.w + r.x * r.x + r.y * r.y + r.z * r.z);
-                    q = Quat{r.w * inv, r.x * inv, r.y * inv, r.z * inv};
+                    float half = angle * 0.5f;                                      // angle / 2 (exact)
+                    float ch = (float)cos((double)half), sh = (float)sin((double)half);
+                    Quat r = quat_mul(Quat{ch, (ang.x / wn) * sh, (ang.y / wn) * sh, (ang.z / wn) * sh}, q);
+                    float nq = sqrtf((float)((((double)(r.w * r.w) + (double)(r.x * r.x)) + (double)(r.y * r.y)) + (double)(r.z * r.z)));
+                    q = Quat{r.w / nq, r.x / nq, r.y / nq, r.z / nq};
                 }
             }
             // -------------------------------------------------------------- missile (environment.py:1069-1117)
             {
                 float mrho = 1.225f, msos = 343.f;
                 if (HAS(HLX_F_ATMOSPHERE)) atmosphere(fmaxf(mpos.z, 0.f), T0, mrho, msos);
-                V3 va = mvel - wind;
-                V3 dacc;
-                if (HAS(HLX_F_MACH_DRAG) && norm(va) > 1e-6f) dacc = mach_drag_accel(va, mrho, msos, 2.0f * 1.5f, 1.0f / 1000.f, dp);
-                else dacc = simple_drag_accel(va, mrho, 1.0f / 1000.f);
-                V3 acc = dacc + grav;
-                if (HAS(HLX_F_EVASION)) {                                           // :1103-1105
+                D3 sum;                                                             // drag + gravity, before evasion
+                if (w64) {
+                    D3 va = to_d3(mvel) - wind;
+                    D3 md;
+                    if (HAS(HLX_F_MACH_DRAG) && dnorm(va) > 1e-6) md = mach_drag_force64(va, mrho, msos, 2.0, dp) * ((0.3 * 1.5) / 0.3) * (1.0 / 1000.0);
+                    else {
+                        double c1 = HAS(HLX_F_ATMOSPHERE) ? (double)(-0.15f * mrho) : (-0.5 * 0.3 * 1.225);
+                        double c2 = c1 * dnorm(va);
+                        md = d3((c2 * va.x) / 1000.0, (c2 * va.y) / 1000.0, (c2 * va.z) / 1000.0);
+                    }
+                    sum = d3(md.x, md.y, md.z + (double)GRAV);
+                } else {
+                    V3 va = mvel - to_v3(wind);
+                    V3 md;
+                    if (HAS(HLX_F_MACH_DRAG) && snorm3(va) > 1e-6f)                  // :1087-1096
+                        md = divc(mach_drag_force(va, mrho, msos, 2.0f, dp) * 1.5f, 1.0 / 1000.0);
+                    else {
+                        float c1 = HAS(HLX_F_ATMOSPHERE) ? (-0.15f * mrho) : (float)(-0.5 * 0.3 * 1.225);
+                        float c2 = c1 * snorm3(va);
+                        md = divc(va * c2, 1.0 / 1000.0);
+                    }
+                    sum = to_d3(v3(md.x, md.y, md.z + GRAV));
+                }
+                if (HAS(HLX_F_EVASION)) {                                           // :1103-1108 (float64)
                     V3 z;
                     if (noise_buf) z = v3(SN[0 * N], SN[1 * N], SN[2 * N]);
                     else { float w_; rng.normals4(RS_EVASION, z.x, z.y, z.z, w_); }
-                    acc = acc + z * 2.0f;
+                    sum = d3(sum.x + (double)z.x * 2.0, sum.y + (double)z.y * 2.0, sum.z + (double)z.z * 2.0);
                 }
-                if (HAS(HLX_F_VALIDATION)) acc = nan_guard(acc, 20.f);
-                mvel = mvel + acc * c.dt;                                           // :1116
+                if (HAS(HLX_F_VALIDATION)) sum = nan_guard(sum, 20.0);
+                mvel = v3((float)((double)mvel.x + sum.x * c.dt64), (float)((double)mvel.y + sum.y * c.dt64),
+                          (float)((double)mvel.z + sum.z * c.dt64));                // :1116
                 mpos = mpos + mvel * c.dt;                                          // :1117
             }
             // -------------------------------------------------------------- wind (environment.py:1119-1129)
             if (HAS(HLX_F_ENH_WIND)) {                                              // physics_models.py:351-387
                 float walt = fmaxf(ipos.z, 0.f);
                 float prof, ti;
-                if (walt <= 10.f) { prof = 1.0f; ti = c.turb * 2.0f; }
+                if (walt <= 10.f) { prof = 1.0f; ti = c.ti_low; }
                 else if (walt <= c.bl_height) {
-                    prof = powf(walt / 10.f, 0.143f);                               // :319-324
-                    ti = c.turb * (1.0f - (walt / c.bl_height) * 0.7f);             // :343-346
-                } else { prof = c.bl_prof; ti = c.turb * 0.3f; }
-                V3 w = v3(c.base_wind[0], c.base_wind[1], c.base_wind[2]) * prof;
+                    prof = powf(divc(walt, 1.0 / 10.0), 0.143f);                    // :319-324
+                    ti = c.ti_mid * (1.0f - (walt / c.bl_height) * 0.7f);           // :343-346
+                } else { prof = c.bl_prof; ti = c.ti_high; }
+                V3 w = v3(c.base_wind[0] * prof, c.base_wind[1] * prof, c.base_wind[2] * prof);
                 V3 z; float gu;
                 if (noise_buf) { z = v3(SN[3 * N], SN[4 * N], SN[5 * N]); gu = SN[6 * N]; }
                 else {
                     float w_; rng.normals4(RS_WIND, z.x, z.y, z.z, w_);
                     gu = u01(rng.raw(RS_STEP_U).w);
                 }
-                if (ti > 0.f) w = w + z * (ti * norm(w) * c.turb_lp);               // :370-378
+                if (ti > 0.f) {                                                     // :370-378
+                    double scale = (double)(ti * snorm3(w));
+                    w = v3((float)((double)w.x + (scale * (double)z.x) * c.turb_lp), (float)((double)w.y + (scale * (double)z.y) * c.turb_lp),
+                           (float)((double)w.z + (scale * (double)z.z) * c.turb_lp));
+                }
                 if (gu < 0.001f) {                                                  // :381-385
                     V3 g; float e;
                     if (noise_buf) { g = v3(SN[7 * N], SN[8 * N], SN[9 * N]); e = SN[10 * N]; }
-                    else {
-                        gust_draws(rng, g, e);
-                    }
-                    w = w + g * (c.gust_scale * e / (norm(g) + 1e-6f));
+                    else gust_draws(rng, g, e);
+                    D3 gd = to_d3(g);
+                    double gn = dnorm(gd) + 1e-6, gmag = c.gust_scale * (double)e;
+                    w = v3((float)((double)w.x + (gd.x / gn) * gmag), (float)((double)w.y + (gd.y / gn) * gmag),
+                           (float)((double)w.z + (gd.z / gn) * gmag));
                 }
-                wind = w;
-            } else if (c.wind_var > 0.f) {                                          // :1127-1129
+                wind = to_d3(w);
+            } else if (simple_wind) {                                               // :1127-1129
                 V3 z;
                 if (noise_buf) z = v3(SN[3 * N], SN[4 * N], SN[5 * N]);
                 else { float w_; rng.normals4(RS_WIND, z.x, z.y, z.z, w_); }
-                V3 bw = v3(c.base_wind[0], c.base_wind[1], c.base_wind[2]);
-                wind = wind * 0.95f + (bw + z * c.wind_var) * 0.05f;
+                auto upd = [&](double w, float base, float zz) {
+                    double t1 = w64 ? 0.95 * w : (double)(0.95f * (float)w);
+                    return t1 + 0.05 * ((double)base + (double)zz * c.wind_var);
+                };
+                wind = d3(upd(wind.x, c.base_wind[0], z.x), upd(wind.y, c.base_wind[1], z.y), upd(wind.z, c.base_wind[2], z.z));
             }
             // -------------------------------------------------------------- intercept / termination (:657-814)
             V3 rel = mpos - ipos;
-            distance = norm(rel);
+            distance = snorm3(rel);
             if (HAS(HLX_F_PROX_FUZE)) intercepted = distance < c.kill_radius;       // :700-703
             else intercepted = distance < a.radius;
             min_distance = (distance < min_distance) ? distance : min_distance;     // :706
@@ -197,7 +253,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
             if (HAS(HLX_F_PROX_FUZE) && min_distance < c.kill_radius) { fuze = true; intercepted = true; } // :715-717
             const bool ground = mpos.z <= 0.f;
             const float gdx = mpos.x - c.target[0], gdy = mpos.y - c.target[1];
-            const bool near_target = sqrtf(gdx * gdx + gdy * gdy) < 500.f;
+            const bool near_target = sqrtf((float)((double)(gdx * gdx) + (double)(gdy * gdy))) < 500.f;
             if (HAS(HLX_F_PRECISION)) {                                             // :752-767
                 if (ground) { terminated = true; hit_target = near_target; }
             } else {                                                                // :769-786
@@ -207,7 +263,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
             if (ipos.z < 0.f) terminated = true;                                    // :789-811
             else if (fuel <= 0.f) terminated = true;
             else if (steps > 1000) {
-                if (distance > last_distance) worsening = min(worsening + 1, 0x1FFF);
+                if (distance > last_distance) worsening = min(worsening + 1, 0xFFF);
                 else worsening = max(0, worsening - 5);
                 last_distance = distance;
                 if (worsening > 500 && distance > 2500.f) terminated = true;
@@ -219,11 +275,11 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     float md = min_distance;
                     if (crossed) {
                         reward = 3000.f;
-                        if (md < a.radius) reward += (a.radius - md) / a.radius * 1000.f;
-                        reward += expf(-md / 25.f) * 500.f;
-                        reward += expf(-md / 10.f) * 1000.f;
-                        reward += expf(-md / 3.f) * 500.f;
-                        reward += (float)(c.max_steps - steps) * 0.3f;
+                        if (md < a.radius) reward = reward + ((a.radius - md) / a.radius) * 1000.f;
+                        reward = reward + expf(divc(-md, 1.0 / 25.0)) * 500.f;
+                        reward = reward + expf(divc(-md, 1.0 / 10.0)) * 1000.f;
+                        reward = reward + expf(divc(-md, 1.0 / 3.0)) * 500.f;
+                        reward = reward + (float)((double)(c.max_steps - steps) * 0.3);
                     } else {
                         reward = fmaxf(-md * 0.5f, -2000.f);
                         if (hit_target) reward -= 1000.f;
@@ -232,19 +288,20 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     }
                 } else {                                                            // :1203-1271
                     float delta = prev_distance - distance;
-                    reward = clampf((delta / c.dt) / 100.f, -0.5f, 2.0f) * 0.5f;
-                    if (distance < 50.f) { reward += delta * 5.f; reward += expf(-distance / 10.f); }
-                    else if (distance < 150.f) reward += delta * 3.f;
-                    else if (distance < 500.f) reward += delta * 1.5f;
-                    else reward += delta * 0.8f;
-                    float isp = norm(ivel);
-                    if (isp > 1.0f && distance > 10.f) reward += dot(ivel * (1.0f / isp), rel * (1.0f / distance)) * 0.3f;
-                    if (HAS(HLX_F_OBS_LOS)) reward += los_a0 * 0.4f;
-                    reward -= 0.2f;
+                    float cv = divc(delta, c.inv_dtf);
+                    reward = clampf(divc(cv, 1.0 / 100.0), -0.5f, 2.0f) * 0.5f;
+                    if (distance < 50.f) { reward = reward + delta * 5.f; reward = reward + expf(divc(-distance, 1.0 / 10.0)) * 1.0f; }
+                    else if (distance < 150.f) reward = reward + delta * 3.f;
+                    else if (distance < 500.f) reward = reward + delta * 1.5f;
+                    else reward = reward + delta * 0.8f;
+                    float isp = snorm3(ivel);
+                    if (isp > 1.0f && distance > 10.f) reward = reward + sdot3(ivel / isp, rel / distance) * 0.3f; // :1241-1250
+                    if (HAS(HLX_F_OBS_LOS)) reward = reward + los_a0 * 0.4f;         // :1256-1264
+                    reward = reward - 0.2f;
                     prev_distance = distance;
                 }
             } else if (intercepted) {                                               // :1274-1282
-                reward = 5000.f + (float)(c.max_steps - steps) * 0.5f;
+                reward = (float)(5000.0 + (double)(c.max_steps - steps) * 0.5);
             } else if (terminated) {                                                // :1284-1296
                 reward = fmaxf(-distance * 0.5f, -2000.f);
                 if (hit_target) reward -= 1000.f;
@@ -252,9 +309,10 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                 else if (fuel <= 0.f) reward -= 300.f;
             } else {                                                                // :1298-1320
                 float delta = prev_distance - distance;
-                reward = clampf((delta / c.dt) / 100.f, -0.5f, 2.0f) * 0.3f;
-                reward += delta * ((distance < 200.f) ? 2.0f : (distance < 500.f) ? 1.0f : 0.5f);
-                reward -= 0.5f;
+                float cv = divc(delta, c.inv_dtf);
+                reward = clampf(divc(cv, 1.0 / 100.0), -0.5f, 2.0f) * 0.3f;
+                reward = reward + delta * ((distance < 200.f) ? 2.0f : (distance < 500.f) ? 1.0f : 0.5f);
+                reward = reward - 0.5f;
                 prev_distance = distance;
             }
             done = terminated || truncated;
@@ -285,12 +343,12 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                         if (a.info.episode_return) a.info.episode_return[i] = ep_return;
                         if (a.info.episode_length) a.info.episode_length[i] = steps;
                     }
-                    // ---------------- spawn (environment.py:375-567)
+                    // ---------------- spawn (environment.py:375-567): float64 draws cast to float32
                     const bool rbuf = a.reset_noise != nullptr;
-                    float u[10];
+                    double u[10];
                     if (rbuf) {
 #pragma unroll
-                        for (int k = 0; k < 10; ++k) u[k] = RN[k * N];
+                        for (int k = 0; k < 10; ++k) u[k] = (double)RN[k * N];
                     } else {
                         uint4 x0 = rng.raw(RS_RESET_U0), x1 = rng.raw(RS_RESET_U1), x2 = rng.raw(RS_RESET_U2);
                         u[0] = u01(x0.x); u[1] = u01(x0.y); u[2] = u01(x0.z); u[3] = u01(x0.w);
@@ -299,41 +357,43 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     }
                     const V3 tp = v3(c.target[0], c.target[1], c.target[2]);
                     if (HAS(HLX_F_SPHERICAL)) {                                     // :390-406
-                        float radius = c.mis_radius[0] + (c.mis_radius[1] - c.mis_radius[0]) * u[0];
-                        float az = (c.mis_az[0] + (c.mis_az[1] - c.mis_az[0]) * u[1]) * 0.017453292519943295f;
-                        float el = (c.mis_el[0] + (c.mis_el[1] - c.mis_el[0]) * u[2]) * 0.017453292519943295f;
-                        float ce = cosf(el);
-                        mpos = tp + v3(radius * ce * cosf(az), radius * ce * sinf(az), radius * sinf(el));
+                        const double PI = 3.141592653589793;
+                        double radius = c.mis_radius[0] + c.mis_radius[1] * u[0];
+                        double az = ((c.mis_az[0] + c.mis_az[1] * u[1]) * PI) / 180.0;
+                        double el = ((c.mis_el[0] + c.mis_el[1] * u[2]) * PI) / 180.0;
+                        mpos = v3((float)((double)tp.x + (radius * cos(el)) * cos(az)), (float)((double)tp.y + (radius * cos(el)) * sin(az)),
+                                  (float)((double)tp.z + radius * sin(el)));
                     } else {                                                        // :409
-                        mpos = v3(c.mis_lo[0] + c.mis_span[0] * u[0], c.mis_lo[1] + c.mis_span[1] * u[1],
-                                  c.mis_lo[2] + c.mis_span[2] * u[2]);
+                        mpos = v3((float)(c.mis_lo[0] + c.mis_span[0] * u[0]), (float)(c.mis_lo[1] + c.mis_span[1] * u[1]),
+                                  (float)(c.mis_lo[2] + c.mis_span[2] * u[2]));
                     }
-                    float speed = c.mis_speed[0] + (c.mis_speed[1] - c.mis_speed[0]) * u[3]; // :415
+                    float speed = (float)(c.mis_speed[0] + c.mis_speed[1] * u[3]);  // :415
                     V3 tt = tp - mpos;
-                    float ttd = norm(tt);
-                    mvel = (ttd > 1e-6f) ? tt * (1.0f / ttd) * speed : v3(0.f, 0.f, 0.f); // :418-423
-                    ipos = v3(c.int_lo[0] + c.int_span[0] * u[4], c.int_lo[1] + c.int_span[1] * u[5],
-                              c.int_lo[2] + c.int_span[2] * u[6]);                  // :445
+                    float ttd = snorm3(tt);
+                    mvel = (ttd > 1e-6f) ? (tt / ttd) * speed : v3(0.f, 0.f, 0.f);  // :418-423
+                    ipos = v3((float)(c.int_lo[0] + c.int_span[0] * u[4]), (float)(c.int_lo[1] + c.int_span[1] * u[5]),
+                              (float)(c.int_lo[2] + c.int_span[2] * u[6]));         // :445
                     V3 rel0 = mpos - ipos;
-                    float reld = norm(rel0);
+                    float reld = snorm3(rel0);
                     if (HAS(HLX_F_TOWARD_MISSILE) && reld > 1e-6f)                  // :452-462
-                        ivel = rel0 * (1.0f / reld) * (c.int_speed[0] + (c.int_speed[1] - c.int_speed[0]) * u[7]);
+                        ivel = (rel0 / reld) * (float)(c.int_speed[0] + c.int_speed[1] * u[7]);
                     else                                                            // :467
-                        ivel = v3(c.ivel_lo[0] + c.ivel_span[0] * u[7], c.ivel_lo[1] + c.ivel_span[1] * u[8],
-                                  c.ivel_lo[2] + c.ivel_span[2] * u[9]);
-                    q = Quat{1.f, 0.f, 0.f, 0.f};                                   // :489-530 rotate +Z onto the LOS
+                        ivel = v3((float)(c.ivel_lo[0] + c.ivel_span[0] * u[7]), (float)(c.ivel_lo[1] + c.ivel_span[1] * u[8]),
+                                  (float)(c.ivel_lo[2] + c.ivel_span[2] * u[9]));
+                    q = Quat{1.f, 0.f, 0.f, 0.f};                                   // :489-530 rotate +Z onto the LOS (float64)
                     if (reld > 1e-6f) {
-                        V3 fd = rel0 * (1.0f / reld);
-                        float axl = sqrtf(fd.x * fd.x + fd.y * fd.y);
-                        if (axl > 1e-6f) {
-                            float half = 0.5f * acosf(clampf(fd.z, -1.f, 1.f));
-                            float sh = sinf(half) / axl;
-                            q = Quat{cosf(half), -fd.y * sh, fd.x * sh, 0.f};
+                        V3 fd = rel0 / reld;
+                        double ax = -(double)fd.y, ay = (double)fd.x;
+                        double axl = sqrt(ax * ax + ay * ay);
+                        if (axl > 1e-6) {
+                            double half = acos(fmin(fmax((double)fd.z, -1.0), 1.0)) / 2.0;
+                            double sh = sin(half);
+                            q = Quat{(float)cos(half), (float)((ax / axl) * sh), (float)((ay / axl) * sh), 0.f};
                         } else if (!(fd.z > 0.f)) q = Quat{0.f, 1.f, 0.f, 0.f};
                     }
                     on_delay = c.o_delay;                                           // constructor value (core.py:292-293)
                     fuel = 100.f;                                                   // :537
-                    wind = v3(c.base_wind[0], c.base_wind[1], c.base_wind[2]);       // :542
+                    wind = d3((double)c.base_wind[0], (double)c.base_wind[1], (double)c.base_wind[2]); // :542
                     thrust_act = v3(0.f, 0.f, 0.f);                                 // :549
                     if (HAS(HLX_F_DOMAIN_RAND)) {                                   // :552-562, physics_randomizer.py
                         float zt, zd, zm, zs;
@@ -343,17 +403,18 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                             float z0_; rng.normals4(RS_DR0, z0_, zt, zd, zm);
                             float z1_, z2_, z3_; rng.normals4(RS_DR1, zs, z1_, z2_, z3_);
                         }
-                        if (HAS(HLX_F_ATMOSPHERE)) T0 += c.dr_var[1] * zt;          // :258-261 (accumulates)
+                        auto mult = [](double var, float z) { return fmin(fmax(1.0 + var * (double)z, 0.1), 3.0); };
+                        if (HAS(HLX_F_ATMOSPHERE)) T0 = (float)((double)T0 + c.dr_var[1] * (double)zt); // :258-261 (accumulates)
                         if (HAS(HLX_F_MACH_DRAG)) {                                 // :270-280
-                            dp.base_cd = 0.3f * clampf(1.0f + c.dr_var[2] * zd, 0.1f, 3.0f);
-                            dp.peak = 3.0f * clampf(1.0f + c.dr_var[3] * zm, 0.1f, 3.0f);
+                            dp.base_cd = (float)(0.3 * mult(c.dr_var[2], zd));
+                            dp.peak = (float)(3.0 * mult(c.dr_var[3], zm));
                         }
                         if (c.o_delay > 0)                                          // :289-297
-                            on_delay = min(10, max(1, (int)(3.0f * clampf(1.0f + c.dr_var[4] * zs, 0.1f, 3.0f))));
+                            on_delay = min(10, max(1, (int)(3.0 * mult(c.dr_var[4], zs))));
                     }
                     steps = 0; ep_return = 0.f;                                     // :565-566
-                    kf_init = false;                                                // core.py:65-69
-                    kxp = v3(0.f, 0.f, 0.f); kxv = kxp;
+                    kf_init = false; kf_x64 = false;                                // core.py:65-69
+                    kxp = d3(0., 0., 0.); kxv = kxp;
                     p_pp = 1000.f; p_pv = 0.f; p_vp = 0.f; p_vv = 1000.f;
                     prev_distance = reld; last_distance = reld; min_distance = reld; // :579-589
                     worsening = 0; crossed = false;
@@ -373,17 +434,17 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     n_on = u01(x.x); n_g = u01(x.y); n_dl = u01(x.z);
                     n_gp = n_gv = v3(0.f, 0.f, 0.f);   // drawn below, only if the ground radar detects
                 }
-                V3 rel = mpos - ipos;
-                float range = norm(rel);
+                const V3 rel = mpos - ipos;
+                const float range = snorm3(rel);
                 bool on_det = !(range > c.radar_range);                             // :539
-                V3 fwd = forward_vec(q);
+                const V3 fwd = forward_vec(q);
                 {
-                    V3 tom = rel * (1.0f / (range + 1e-6f));                        // :546
-                    float beam_angle = acosf(clampf(dot(fwd, tom), -1.f, 1.f));     // :547
-                    if (beam_angle > a.half_beam) on_det = false;                   // :553
+                    V3 tom = rel / (range + 1e-6f);                                 // :546
+                    float beam_angle = acosf(clampf(sdot3(fwd, tom), -1.f, 1.f));   // :547
+                    if ((double)beam_angle > a.half_beam) on_det = false;           // :553 (float64 comparison)
                 }
                 if (on_det) {                                                       // :559-566
-                    float aq = c.radar_quality * (1.0f - (range / c.radar_range) * 0.5f) * a.on_rel;
+                    float aq = (c.radar_quality * (1.0f - (range / c.radar_range) * 0.5f)) * a.on_rel;
                     if (n_on > aq) on_det = false;
                 }
                 V3 d_on = rel;
@@ -404,15 +465,15 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                 const V3 gp = v3(c.ground_pos[0], c.ground_pos[1], c.ground_pos[2]);
                 if (HAS(HLX_F_GROUND)) {
                     V3 g2m = mpos - gp;
-                    float grange = norm(g2m);
+                    float grange = snorm3(g2m);
                     g_det = !(grange > c.g_max_range);                              // :396
-                    if (g_det && grange > 1e-6f) {                                  // :401-406
-                        float el = asinf(clampf(g2m.z / grange, -1.f, 1.f));
+                    if (g_det && grange > 1e-6f) {                                  // :401-406 (float64 comparisons)
+                        double el = (double)asinf(clampf(g2m.z / grange, -1.f, 1.f));
                         if (el < c.g_min_elev || el > c.g_max_elev) g_det = false;
                     }
                     if (mpos.z < 50.f) g_det = false;                               // :409
                     if (g_det) {                                                    // :413-418
-                        float dpq = c.g_base_q * (1.0f - (grange / c.g_max_range) * 0.4f) * c.weather * a.g_rel;
+                        float dpq = ((c.g_base_q * (1.0f - (grange / c.g_max_range) * 0.4f)) * c.weather) * a.g_rel;
                         if (n_g > dpq) g_det = false;
                         else {
                             if (!from_buf) {
@@ -420,87 +481,115 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                                 rng.normals4(pass == 0 ? RS_GPOS : RS_RESET_GPOS, n_gp.x, n_gp.y, n_gp.z, w0_);
                                 rng.normals4(pass == 0 ? RS_GVEL : RS_RESET_GVEL, n_gv.x, n_gv.y, n_gv.z, w1_);
                             }
-                            g_pos = rel + n_gp * c.g_range_acc;                     // :422-428
-                            g_vel = (mvel - ivel) + n_gv * c.g_vel_acc;             // :429
+                            // :422-429 float64 measurement, held in float32 in the ring (quantisation ~1e-4 m
+                            // against 10 m of measurement noise; it does not accumulate in the filter)
+                            g_pos = v3((float)((double)rel.x + c.g_range_acc * (double)n_gp.x), (float)((double)rel.y + c.g_range_acc * (double)n_gp.y),
+                                       (float)((double)rel.z + c.g_range_acc * (double)n_gp.z));
+                            V3 rv = mvel - ivel;
+                            g_vel = v3((float)((double)rv.x + c.g_vel_acc * (double)n_gv.x), (float)((double)rv.y + c.g_vel_acc * (double)n_gv.y),
+                                       (float)((double)rv.z + c.g_vel_acc * (double)n_gv.z));
                             g_q = dpq;
                         }
                     }
                 }
                 V3 d_gp = g_pos, d_gv = g_vel;
                 float d_gq = g_q;
-                bool d_g_det = g_det;
+                bool d_g_det = g_det, d_g64 = g_det;    // d_g64: the delayed sample is a real (float64) measurement
                 if (HAS(HLX_F_GROUND) && c.g_delay > 0) {                           // :609-627 ground delay ring
                     g_s0 = make_float4(g_pos.x, g_pos.y, g_pos.z, g_q);
-                    g_s1 = make_float4(g_vel.x, g_vel.y, g_vel.z, 0.f);
-                    d_gp = v3(0.f, 0.f, 0.f); d_gv = d_gp; d_gq = 0.f; d_g_det = false;
+                    g_s1 = make_float4(g_vel.x, g_vel.y, g_vel.z, g_det ? 1.f : 0.f);
+                    d_gp = v3(0.f, 0.f, 0.f); d_gv = d_gp; d_gq = 0.f; d_g_det = false; d_g64 = false;
                     if (pass == 0 && steps >= c.g_delay) {
                         int slot = (int)((t + 1ull) % (unsigned long long)g_cap);   // == (t - g_delay) mod g_cap
                         const float4* R = a.gring + ((size_t)slot * 2) * N + i;
                         float4 s0 = R[0], s1 = R[N];
                         d_gp = v3(s0.x, s0.y, s0.z); d_gq = s0.w; d_gv = v3(s1.x, s1.y, s1.z);
+                        d_g64 = s1.w != 0.f;
                         d_g_det = g_det;                                            // :626 CURRENT flag (reference quirk)
                     }
                 }
                 // ---- datalink (core.py:440-474)
                 float datalink = 0.f;
                 if (HAS(HLX_F_GROUND)) {
-                    float lr = norm(ipos - gp);
-                    if (!(lr > c.max_datalink) && !(n_dl < c.packet_loss)) {
+                    float lr = snorm3(ipos - gp);
+                    if (!(lr > c.max_datalink) && !((double)n_dl < c.packet_loss)) {
                         float x = lr / c.max_datalink;
-                        float dop = 1.0f - fminf(norm(ivel) / 1000.f, 0.3f);
-                        datalink = clampf((1.0f - x * x) * dop * 0.95f, 0.f, 1.f);
+                        float vr = divc(snorm3(ivel), 1.0 / 1000.0);
+                        float dop = (0.3f < vr) ? (float)(1.0 - 0.3) : (1.0f - vr);
+                        datalink = clampf(((1.0f - x * x) * dop) * 0.95f, 0.f, 1.f);
                     }
                 }
-                // ---- fusion confidence (core.py:476-509)
-                const float on_q = d_on_det ? c.radar_quality : 0.f;
+                // ---- fusion confidence (core.py:476-509) - pure output
                 float fusion;
                 if (!d_on_det && !d_g_det) fusion = 0.f;
-                else if (!d_g_det) fusion = on_q * 0.5f;
+                else if (!d_g_det) fusion = (float)(c.radar_quality64 * 0.5);
                 else if (!d_on_det) fusion = d_gq * 0.6f;
                 else {
-                    float agree = 1.0f - fminf(norm(d_on - d_gp) / 200.f, 1.0f);
-                    fusion = clampf(0.35f * on_q + 0.50f * d_gq + 0.15f * agree, 0.f, 1.f);
+                    float agree = 1.0f - fminf(fnorm(d_on - d_gp) / 200.f, 1.0f);
+                    fusion = clampf((float)(0.35 * c.radar_quality64) + 0.50f * d_gq + 0.15f * agree, 0.f, 1.f);
                 }
                 if (pass == 0) det_bits = (d_on_det ? 32u : 0u) | (d_g_det ? 64u : 0u);
 
                 // ======================================================== core.py:693-1032 compute()
+                // measurement fusion + Kalman filter mirror the reference's dtype flow (float32 until a
+                // float64 ground measurement is absorbed, float64 afterwards): core.py:732-774, :91-116
                 bool have_track;
-                V3 frp = v3(0.f, 0.f, 0.f), frv = frp;
-                if (d_on_det || d_g_det) {                                          // :732-759
-                    V3 fused;
-                    if (d_on_det && d_g_det) fused = (d_on * c.radar_quality + d_gp * d_gq) * (1.0f / (c.radar_quality + d_gq));
-                    else if (d_on_det) fused = d_on;
-                    else fused = d_gp;
-                    V3 z = ipos + fused;                                            // :749
-                    if (!kf_init) { kxp = z; kxv = v3(0.f, 0.f, 0.f); kf_init = true; } // core.py:93-96
-                    else {                                                          // core.py:98-116 on 2x2 blocks
-                        float sinv = 1.0f / (p_pp + 400.f);
-                        float kp = p_pp * sinv, kv = p_vp * sinv;
-                        V3 y = z - kxp;
-                        kxp = kxp + y * kp;
-                        kxv = kxv + y * kv;
-                        float omk = 1.0f - kp;
-                        float npp = omk * p_pp, npv = omk * p_pv;
-                        float nvp = p_vp - kv * p_pp, nvv = p_vv - kv * p_pv;
+                if (d_on_det || d_g_det) {
+                    D3 z;
+                    bool m64;
+                    if (d_on_det && d_g_det) {
+                        m64 = d_g64;
+                        if (m64) {
+                            double total = (double)(c.radar_quality + d_gq);
+                            z = d3(((double)(d_on.x * c.radar_quality) + (double)d_gp.x * (double)d_gq) / total,
+                                   ((double)(d_on.y * c.radar_quality) + (double)d_gp.y * (double)d_gq) / total,
+                                   ((double)(d_on.z * c.radar_quality) + (double)d_gp.z * (double)d_gq) / total);
+                        } else {   // stale zero sample: weight 0.0 (python float) -> float32 arithmetic
+                            float total = (float)c.radar_quality64;
+                            z = to_d3(v3((d_on.x * c.radar_quality) / total, (d_on.y * c.radar_quality) / total,
+                                         (d_on.z * c.radar_quality) / total));
+                        }
+                    } else if (d_on_det) { m64 = false; z = to_d3(d_on); }
+                    else { m64 = d_g64; z = to_d3(d_gp); }
+                    z = d3(rr((double)ipos.x + z.x, m64), rr((double)ipos.y + z.y, m64), rr((double)ipos.z + z.z, m64)); // :749
+                    if (!kf_init) {                                                 // core.py:93-96
+                        kxp = d3((double)(float)z.x, (double)(float)z.y, (double)(float)z.z);
+                        kxv = d3(0., 0., 0.);
+                        kf_init = true;
+                    } else {                                                        // core.py:98-116 on the 2x2 blocks
+                        const bool y64 = m64 || kf_x64;
+                        const float sinv = 1.0f / (p_pp + 400.f);
+                        const float kp = p_pp * sinv, kv = p_vp * sinv;
+                        D3 y = d3(rr(z.x - kxp.x, y64), rr(z.y - kxp.y, y64), rr(z.z - kxp.z, y64));
+                        kxp = d3(rr(kxp.x + rr((double)kp * y.x, y64), y64), rr(kxp.y + rr((double)kp * y.y, y64), y64),
+                                 rr(kxp.z + rr((double)kp * y.z, y64), y64));
+                        kxv = d3(rr(kxv.x + rr((double)kv * y.x, y64), y64), rr(kxv.y + rr((double)kv * y.y, y64), y64),
+                                 rr(kxv.z + rr((double)kv * y.z, y64), y64));
+                        kf_x64 = y64;
+                        const float omk = 1.0f - kp, nkv = 0.f - kv;
+                        const float npp = omk * p_pp, npv = omk * p_pv;
+                        const float nvp = nkv * p_pp + p_vp, nvv = nkv * p_pv + p_vv;
                         p_pp = npp; p_pv = npv; p_vp = nvp; p_vv = nvv;
                     }
                     have_track = true;
                 } else {                                                            // :760-774
                     if (kf_init) {                                                  // core.py:80-89 predict
-                        kxp = kxp + kxv * c.dt;
-                        float a_pp = p_pp + c.dt * p_vp, a_pv = p_pv + c.dt * p_vv;
-                        p_pp = (a_pp + a_pv * c.dt) + c.q11;
-                        p_pv = a_pv + c.q12;
-                        p_vp = (p_vp + p_vv * c.dt) + c.q12;
-                        p_vv = p_vv + c.q22;
+                        const double dtf = (double)c.dt;
+                        kxp = d3(rr(kxp.x + rr(dtf * kxv.x, kf_x64), kf_x64), rr(kxp.y + rr(dtf * kxv.y, kf_x64), kf_x64),
+                                 rr(kxp.z + rr(dtf * kxv.z, kf_x64), kf_x64));
+                        const float a_pp = p_pp + c.dt * p_vp, a_pv = p_pv + c.dt * p_vv;
+                        const float n_pp = a_pp + a_pv * c.dt, n_vp = p_vp + p_vv * c.dt;
+                        p_pp = n_pp + c.q11; p_pv = a_pv + c.q12; p_vp = n_vp + c.q12; p_vv = p_vv + c.q22;
                     }
                     have_track = kf_init;
                 }
-                if (have_track) { frp = kxp - ipos; frv = kxv - ivel; }
+                // ---- observation vector: pure outputs, ordinary fast float32 from here on
                 const float inv_mr = 1.0f / c.max_range, inv_mv = 1.0f / c.max_velocity;
                 if (have_track) {                                                   // :778-906
-                    float rrange = norm(frp);
-                    float closing = -dot(frp, frv) / (rrange + 1e-6f);              // :786
+                    const V3 frp = to_v3(d3(kxp.x - (double)ipos.x, kxp.y - (double)ipos.y, kxp.z - (double)ipos.z));
+                    const V3 frv = to_v3(d3(kxv.x - (double)ivel.x, kxv.y - (double)ivel.y, kxv.z - (double)ivel.z));
+                    const float rrange = fnorm(frp);
+                    const float closing = -fdot(frp, frv) / (rrange + 1e-6f);       // :786
                     if (HAS(HLX_F_OBS_LOS)) {                                       // :791-868
                         row[0] = clampf(rrange * inv_mr, 0.f, 1.f);
                         row[1] = clampf(closing * inv_mv, -1.f, 1.f);
@@ -508,46 +597,46 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                         V3 rate = (frv - lu * closing) * (1.0f / (rrange + 1e-6f)); // :810-811
                         V3 h, v;
                         los_basis(lu, h, v);
-                        row[2] = clampf(dot(rate, h) * 2.0f, -1.f, 1.f);            // :844-845 (/0.5)
-                        row[3] = clampf(dot(rate, v) * 2.0f, -1.f, 1.f);
-                        float ivm = norm(ivel);
-                        row[4] = (ivm > 1e-6f) ? dot(ivel * (1.0f / ivm), lu) : 0.f; // :852-858
+                        row[2] = clampf(fdot(rate, h) * 2.0f, -1.f, 1.f);           // :844-845 (/0.5)
+                        row[3] = clampf(fdot(rate, v) * 2.0f, -1.f, 1.f);
+                        float ivm = fnorm(ivel);
+                        row[4] = (ivm > 1e-6f) ? fdot(ivel, lu) / ivm : 0.f;        // :852-858
                         V3 tv = frv + ivel;                                         // :861
-                        float tvm = norm(tv);
-                        row[5] = (tvm > 1e-6f) ? -dot(tv * (1.0f / tvm), lu) : 0.f;
+                        float tvm = fnorm(tv);
+                        row[5] = (tvm > 1e-6f) ? -fdot(tv, lu) / tvm : 0.f;
                         row[6] = clampf(ivm * inv_mv, 0.f, 1.f);                    // :924-925
-                        row[7] = clampf(dot(ivel, h) * inv_mv, -1.f, 1.f);          // :948-953
-                        row[8] = clampf(dot(ivel, v) * inv_mv, -1.f, 1.f);
+                        row[7] = clampf(fdot(ivel, h) * inv_mv, -1.f, 1.f);         // :948-953
+                        row[8] = clampf(fdot(ivel, v) * inv_mv, -1.f, 1.f);
                     } else if (HAS(HLX_F_OBS_BODY)) {                               // :870-876
                         V3 r = right_vec(q), up = up_vec(q);
-                        row[0] = clampf(dot(frp, fwd) * inv_mr, -1.f, 1.f);
-                        row[1] = clampf(dot(frp, r) * inv_mr, -1.f, 1.f);
-                        row[2] = clampf(dot(frp, up) * inv_mr, -1.f, 1.f);
-                        row[3] = clampf(dot(frv, fwd) * inv_mv, -1.f, 1.f);
-                        row[4] = clampf(dot(frv, r) * inv_mv, -1.f, 1.f);
-                        row[5] = clampf(dot(frv, up) * inv_mv, -1.f, 1.f);
+                        row[0] = clampf(fdot(frp, fwd) * inv_mr, -1.f, 1.f);
+                        row[1] = clampf(fdot(frp, r) * inv_mr, -1.f, 1.f);
+                        row[2] = clampf(fdot(frp, up) * inv_mr, -1.f, 1.f);
+                        row[3] = clampf(fdot(frv, fwd) * inv_mv, -1.f, 1.f);
+                        row[4] = clampf(fdot(frv, r) * inv_mv, -1.f, 1.f);
+                        row[5] = clampf(fdot(frv, up) * inv_mv, -1.f, 1.f);
                     } else {                                                        // :878-882
                         row[0] = clampf(frp.x * inv_mr, -1.f, 1.f); row[1] = clampf(frp.y * inv_mr, -1.f, 1.f);
                         row[2] = clampf(frp.z * inv_mr, -1.f, 1.f); row[3] = clampf(frv.x * inv_mv, -1.f, 1.f);
                         row[4] = clampf(frv.y * inv_mv, -1.f, 1.f); row[5] = clampf(frv.z * inv_mv, -1.f, 1.f);
                     }
-                    row[13] = (closing > 0.f) ? clampf(1.0f - (rrange / closing) / 100.f, -1.f, 1.f) : -1.f; // :885-889
-                    float tq = clampf(1.0f - (p_pp + p_pp + p_pp) / 10000.f, 0.f, 1.f); // :892-893 trace of 3 equal blocks
+                    row[13] = (closing > 0.f) ? clampf(1.0f - (rrange / closing) * 0.01f, -1.f, 1.f) : -1.f; // :885-889
+                    float tq = clampf(1.0f - ((p_pp + p_pp) + p_pp) * 1e-4f, 0.f, 1.f); // :892-893 trace of 3 equal blocks
                     if (d_on_det) tq *= c.radar_quality;                            // :894-895
                     row[14] = tq;
                     row[15] = clampf(closing * inv_mv, -1.f, 1.f);                  // :899
-                    row[16] = (rrange > 1e-6f) ? dot(fwd, frp) / rrange : 1.0f;     // :902-906
+                    row[16] = (rrange > 1e-6f) ? fdot(fwd, frp) / rrange : 1.0f;    // :902-906
                 } else {                                                            // :907-917
 #pragma unroll
                     for (int k = 0; k < 6; ++k) row[k] = -2.0f;
                     row[13] = -1.0f; row[14] = 0.f; row[15] = 0.f; row[16] = 0.f;
-                    if (HAS(HLX_F_OBS_LOS)) { row[6] = clampf(norm(ivel) * inv_mv, 0.f, 1.f); row[7] = 0.f; row[8] = 0.f; }
+                    if (HAS(HLX_F_OBS_LOS)) { row[6] = clampf(fnorm(ivel) * inv_mv, 0.f, 1.f); row[7] = 0.f; row[8] = 0.f; }
                 }
                 if (HAS(HLX_F_OBS_BODY)) {                                          // :959-962
                     V3 r = right_vec(q), up = up_vec(q);
-                    row[6] = clampf(dot(ivel, fwd) * inv_mv, -1.f, 1.f);
-                    row[7] = clampf(dot(ivel, r) * inv_mv, -1.f, 1.f);
-                    row[8] = clampf(dot(ivel, up) * inv_mv, -1.f, 1.f);
+                    row[6] = clampf(fdot(ivel, fwd) * inv_mv, -1.f, 1.f);
+                    row[7] = clampf(fdot(ivel, r) * inv_mv, -1.f, 1.f);
+                    row[8] = clampf(fdot(ivel, up) * inv_mv, -1.f, 1.f);
                 } else if (!HAS(HLX_F_OBS_LOS)) {                                   // :964
                     row[6] = clampf(ivel.x * inv_mv, -1.f, 1.f); row[7] = clampf(ivel.y * inv_mv, -1.f, 1.f);
                     row[8] = clampf(ivel.z * inv_mv, -1.f, 1.f);
@@ -559,20 +648,20 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     row[10] = asinf(clampf(2.f * (q.w * q.y - q.z * q.x), -1.f, 1.f)) * inv_pi;
                     row[11] = atan2f(2.f * (q.w * q.z + q.x * q.y), 1.f - 2.f * (q.y * q.y + q.z * q.z)) * inv_pi;
                 }
-                row[12] = clampf(fuel / 100.f, 0.f, 1.f);                           // :977
+                row[12] = clampf(fuel * 0.01f, 0.f, 1.f);                           // :977
                 if (d_g_det && datalink > 0.1f) {                                   // :980-1018
                     if (HAS(HLX_F_OBS_LOS)) {
-                        float gr = norm(d_gp);
-                        float gc = -dot(d_gp, d_gv) / (gr + 1e-6f);
+                        float gr = fnorm(d_gp);
+                        float gc = -fdot(d_gp, d_gv) / (gr + 1e-6f);
                         row[17] = clampf(gr * inv_mr, 0.f, 1.f);
                         row[18] = clampf(gc * inv_mv, -1.f, 1.f);
-                        row[19] = (gr > 1e-6f) ? clampf(norm(d_gv - d_gp * (gc / gr)) / gr * 2.0f, 0.f, 1.f) : 0.f;
+                        row[19] = (gr > 1e-6f) ? clampf(fnorm(d_gv - d_gp * (gc / gr)) / gr * 2.0f, 0.f, 1.f) : 0.f;
                         row[20] = 0.f; row[21] = 0.f; row[22] = 0.f;
                     } else if (HAS(HLX_F_OBS_BODY)) {
                         V3 r = right_vec(q), up = up_vec(q);
-                        row[17] = clampf(dot(d_gp, fwd) * inv_mr, -1.f, 1.f); row[18] = clampf(dot(d_gp, r) * inv_mr, -1.f, 1.f);
-                        row[19] = clampf(dot(d_gp, up) * inv_mr, -1.f, 1.f); row[20] = clampf(dot(d_gv, fwd) * inv_mv, -1.f, 1.f);
-                        row[21] = clampf(dot(d_gv, r) * inv_mv, -1.f, 1.f); row[22] = clampf(dot(d_gv, up) * inv_mv, -1.f, 1.f);
+                        row[17] = clampf(fdot(d_gp, fwd) * inv_mr, -1.f, 1.f); row[18] = clampf(fdot(d_gp, r) * inv_mr, -1.f, 1.f);
+                        row[19] = clampf(fdot(d_gp, up) * inv_mr, -1.f, 1.f); row[20] = clampf(fdot(d_gv, fwd) * inv_mv, -1.f, 1.f);
+                        row[21] = clampf(fdot(d_gv, r) * inv_mv, -1.f, 1.f); row[22] = clampf(fdot(d_gv, up) * inv_mv, -1.f, 1.f);
                     } else {
                         row[17] = clampf(d_gp.x * inv_mr, -1.f, 1.f); row[18] = clampf(d_gp.y * inv_mr, -1.f, 1.f);
                         row[19] = clampf(d_gp.z * inv_mr, -1.f, 1.f); row[20] = clampf(d_gv.x * inv_mv, -1.f, 1.f);
@@ -591,19 +680,22 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
 
         // ---------------------------------------------------------------------- store state + rings
         if (MODE == 0 || done) {
-            packed = (uint32_t)steps | ((uint32_t)worsening << 13) | ((uint32_t)crossed << 26) |
-                     ((uint32_t)kf_init << 27) | ((uint32_t)on_delay << 28);
+            packed = (uint32_t)steps | ((uint32_t)worsening << 13) | ((uint32_t)crossed << 25) |
+                     ((uint32_t)kf_init << 26) | ((uint32_t)kf_x64 << 27) | ((uint32_t)on_delay << 28);
             A[G_IPOS * N] = make_float4(ipos.x, ipos.y, ipos.z, fuel);
             A[G_IVEL * N] = make_float4(ivel.x, ivel.y, ivel.z, prev_distance);
             A[G_QUAT * N] = make_float4(q.w, q.x, q.y, q.z);
             A[G_MPOS * N] = make_float4(mpos.x, mpos.y, mpos.z, min_distance);
             A[G_MVEL * N] = make_float4(mvel.x, mvel.y, mvel.z, last_distance);
-            A[G_WIND * N] = make_float4(wind.x, wind.y, wind.z, __uint_as_float(packed));
-            A[G_KFP * N] = make_float4(kxp.x, kxp.y, kxp.z, p_pp);
-            A[G_KFV * N] = make_float4(kxv.x, kxv.y, kxv.z, p_pv);
-            A[G_MISC * N] = make_float4(p_vp, p_vv, ep_return, T0);
+            AD[G_W0 * N] = make_double2(wind.x, wind.y);
+            A[G_W1 * N] = make_float4(__int_as_float(__double2loint(wind.z)), __int_as_float(__double2hiint(wind.z)),
+                                      __uint_as_float(packed), ep_return);
+            AD[G_KF0 * N] = make_double2(kxp.x, kxp.y);
+            AD[G_KF1 * N] = make_double2(kxp.z, kxv.x);
+            AD[G_KF2 * N] = make_double2(kxv.y, kxv.z);
+            A[G_KFP * N] = make_float4(p_pp, p_pv, p_vp, p_vv);
             if (HAS(HLX_F_THRUST_LAG)) A[G_THRUST * N] = make_float4(thrust_act.x, thrust_act.y, thrust_act.z, 0.f);
-            if (HAS(HLX_F_DOMAIN_RAND)) A[G_DR * N] = make_float4(dp.base_cd, dp.peak, 0.f, 0.f);
+            if (HAS(HLX_F_DOMAIN_RAND)) A[G_MISC * N] = make_float4(T0, dp.base_cd, dp.peak, 0.f);
             if (c.o_delay > 0) a.oring[(size_t)(t % (unsigned long long)o_cap) * N + i] = on_sample;
             if (HAS(HLX_F_GROUND) && c.g_delay > 0) {
                 float4* R = a.gring + ((size_t)(t % (unsigned long long)g_cap) * 2) * N + i;

@@ -74,26 +74,28 @@ typedef enum hlx_flags {
 } hlx_flags;
 
 /* Flat parameter set = the EFFECTIVE values the reference's constructor arrives at
- * (hlynr_intercept_amd/config.py resolves a reference config dict into this). */
+ * (hlynr_intercept_amd/config.py resolves a reference config dict into this).  The reference's
+ * parameters are Python floats, i.e. doubles; they stay doubles here so that the library can derive
+ * its float32 / float64 kernel constants with the roundings the reference's arithmetic implies. */
 typedef struct hlx_config {
     uint32_t flags;
     int32_t max_steps;
-    float dt, max_range, max_velocity;
-    float target_pos[3];
-    float mis_pos_lo[3], mis_pos_hi[3];
-    float mis_radius[2], mis_azimuth_deg[2], mis_elevation_deg[2], mis_speed[2];
-    float int_pos_lo[3], int_pos_hi[3], int_vel_lo[3], int_vel_hi[3], int_speed[2];
-    float subsonic_mach, supersonic_mach, transonic_peak_multiplier, supersonic_multiplier;
-    float base_wind[3], wind_variability, boundary_layer_height, turbulence_intensity, gust_scale, thrust_tau;
-    float dr_variations[13];
-    float proximity_kill_radius;
-    float radar_quality, radar_range, radar_beam_width;
     int32_t onboard_delay;          /* samples, 0 = no onboard delay ring */
-    float ground_pos[3], ground_max_range, ground_min_elev, ground_max_elev;
-    float ground_range_accuracy, ground_velocity_accuracy, ground_base_quality;
-    float max_datalink_range, datalink_packet_loss, weather_factor;
     int32_t ground_delay;           /* samples, 0 = no ground delay ring */
-    /* curriculum schedules, evaluated host-side in double by hlx_set_global_step */
+    double dt, max_range, max_velocity;
+    double target_pos[3];
+    double mis_pos_lo[3], mis_pos_hi[3];
+    double mis_radius[2], mis_azimuth_deg[2], mis_elevation_deg[2], mis_speed[2];
+    double int_pos_lo[3], int_pos_hi[3], int_vel_lo[3], int_vel_hi[3], int_speed[2];
+    double subsonic_mach, supersonic_mach, transonic_peak_multiplier, supersonic_multiplier;
+    double base_wind[3], wind_variability, boundary_layer_height, turbulence_intensity, gust_scale, thrust_tau;
+    double dr_variations[13];
+    double proximity_kill_radius;
+    double radar_quality, radar_range, radar_beam_width;
+    double ground_pos[3], ground_max_range, ground_min_elev, ground_max_elev;
+    double ground_range_accuracy, ground_velocity_accuracy, ground_base_quality;
+    double max_datalink_range, datalink_packet_loss, weather_factor;
+    /* curriculum schedules, evaluated host-side by hlx_set_global_step */
     double initial_radius, final_radius, curriculum_steps;
     double rc_beam[4], rc_onboard[4], rc_ground[4], rc_noise[4]; /* {initial, final, start, end} */
 } hlx_config;
@@ -116,15 +118,17 @@ typedef struct hlx_env_state {
     float int_pos[3], int_vel[3], int_quat[4], fuel;
     float thrust_actual[3];
     float mis_pos[3], mis_vel[3];
-    float wind[3];
     float prev_distance, min_distance, last_distance;
     int32_t steps, worsening, crossed, kf_init;
-    float kf_x[6];
+    int32_t kf_x_is64;                  /* the reference's Kalman state array has become float64 (core.py:112) */
+    int32_t pad0;
+    double wind[3];                     /* float64 in the reference's simple-wind mode (environment.py:1127-1129) */
+    double kf_x[6];
     float kf_P[4];                      /* p_pp, p_pv, p_vp, p_vv : covariance is 3 identical 2x2 blocks */
     int32_t on_delay, on_len;
     float on_ring[HLX_RING_CAP][4];     /* oldest -> newest : rel_pos xyz, detected(0/1) */
     int32_t g_len;
-    float g_ring[HLX_RING_CAP][8];      /* oldest -> newest : rel_pos xyz, quality, rel_vel xyz, pad */
+    float g_ring[HLX_RING_CAP][8];      /* oldest -> newest : rel_pos xyz, quality, rel_vel xyz, sample-was-a-detection flag */
     float T0, base_cd, transonic_peak;  /* constants touched by domain randomisation */
     float ep_return;
 } hlx_env_state;

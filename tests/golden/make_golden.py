@@ -410,6 +410,10 @@ def run_case(name, env_cfg, n_steps, seed, policy="random", tweak=None, global_s
         elif policy == "coast":
             a = np.zeros(6, np.float32)
             a[3:6] = arng.uniform(-1, 1, 3)
+        elif policy == "hover":
+            a = np.zeros(6, np.float32)
+            a[2] = 0.49
+            a += 0.02 * arng.standard_normal(6).astype(np.float32)
         elif callable(policy):
             a = policy(env, arng, t)
         else:
@@ -509,12 +513,11 @@ def tw_look_away(env):
     env.interceptor_state["orientation"][:] = np.array([0.0, 1.0, 0.0, 0.0], np.float32)
 
 
-def tw_late(env):
-    # force the step>1000 smart-early-termination bookkeeping without 1000 recorded steps
-    env.steps = 1000
-    env._distance_worsening_count = 497
+def tw_flyaway(env):
+    # missile far away and receding: after step 1000 the "distance worsening" counter climbs every step and
+    # the smart early termination (environment.py:795-811) fires at step 1501
     env.missile_state["position"] += np.array([1500.0, 1500.0, 900.0], np.float32)
-    env.missile_state["velocity"][:] = np.array([60.0, 60.0, 5.0], np.float32)
+    env.missile_state["velocity"][:] = np.array([150.0, 150.0, 30.0], np.float32)
     d = np.linalg.norm(env.missile_state["position"] - env.interceptor_state["position"])
     env._prev_distance = np.float32(d)
     env._last_distance = env._prev_distance
@@ -600,8 +603,8 @@ def main():
              tweak=tw_close, policy="coast")
     run_case("edge_mach_sweep", S("hard", "v2"), 200, 1057, tweak=tw_fast, policy="pursuit")
     run_case("edge_look_away", S("medium", "v2"), 120, 1058, tweak=tw_look_away, policy="coast")
-    run_case("edge_early_termination", S("medium", "base", {"max_steps": 4000}), 60, 1059, tweak=tw_late,
-             policy="coast")
+    run_case("edge_early_termination", S("medium", "base", {"max_steps": 4000}), 1560, 1059, tweak=tw_flyaway,
+             policy="hover", state_every=50)
     run_case("edge_blind_kf_uninit", S("medium", "v2"), 80, 1060, tweak=tw_blind, policy="coast")
     run_case("edge_radar_curriculum_mid", S("medium", "base"), 120, 1061, global_step=6500000,
              policy=spin_then_random)

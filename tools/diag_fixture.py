@@ -1,0 +1,52 @@
+"""Diagnostic: replay golden fixtures on the GPU and print per-observation-index errors."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from tests.golden_util import load_fixture
+from hlynr_intercept_amd.config import resolve_config
+from hlynr_intercept_amd.vec_env import HlynrVecEnv
+
+for name in sys.argv[1:]:
+    fx = load_fixture(name)
+    rc = resolve_config(fx["config"])
+    n = 1
+    env = HlynrVecEnv(resolved=rc, num_envs=n)
+    if fx["global_step_or_none"] is not None:
+        env.set_training_step_count(fx["global_step_or_none"])
+    dev = env.device
+    T = len(fx["action"])
+    sn_all = torch.tensor(np.nan_to_num(fx["step_noise"], nan=0.5), dtype=torch.float32, device=dev)[:, :, None].contiguous()
+    rn0 = torch.tensor(np.nan_to_num(fx["reset_noise0"], nan=0.5), dtype=torch.float32, device=dev)[:, None].contiguous()
+    if "reset_noise" in fx:
+        rn_all = torch.tensor(np.nan_to_num(fx["reset_noise"], nan=0.5), dtype=torch.float32, device=dev)[:, :, None].contiguous()
+    actions = torch.tensor(fx["action"], dtype=torch.float32, device=dev)[:, None, :].contiguous()
+    env.set_noise(sn_all[0], rn0)
+    env.reset_torch()
+    st = env.get_state()
+    for fld in ("int_pos", "int_vel", "int_quat", "mis_pos", "mis_vel"):
+        arr = getattr(st[0], fld)
+        for k, x in enumerate(fx["init_" + fld]):
+            arr[k] = float(x)
+    st[0].fuel = float(fx["init_fuel"]); st[0].steps = int(fx["init_steps"])
+    st[0].prev_distance = float(fx["init_prev_distance"]); st[0].min_distance = float(fx["init_min_distance"])
+    st[0].last_distance = float(fx["init_last_distance"]); st[0].worsening = int(fx["init_worsening"])
+    st[0].crossed = int(fx["init_crossed"])
+    env.set_state(st)
+    err = np.zeros(26); when = np.zeros(26, int)
+    k_reset = 0
+    first_bad = None
+    for t in range(T):
+        rn = rn_all[k_reset] if fx["did_reset"][t] else rn0
+        env.set_noise(sn_all[t], rn)
+        obs, rew, term, trunc, info = env.step_torch(actions[t])
+        o = (info["terminal_observation"] if fx["did_reset"][t] else obs).cpu().numpy()[0]
+        e = np.abs(o - fx["obs"][t])
+        upd = e > err
+        err[upd] = e[upd]; when[upd] = t
+        if first_bad is None and e.max() > 2e-5:
+            first_bad = (t, int(e.argmax()), float(e.max()), o[e.argmax()], fx["obs"][t][e.argmax()])
+        if fx["did_reset"][t]:
+            k_reset += 1
+    print(name, "first_bad", first_bad)
+    print("  idx:err@t ", " ".join(f"{i}:{err[i]:.1e}@{when[i]}" for i in range(26) if err[i] > 2e-6))
+    env.close()
