@@ -56,7 +56,7 @@ class HlxEnvState(C.Structure):
         ("steps", i32), ("worsening", i32), ("crossed", i32), ("kf_init", i32), ("kf_x_is64", i32), ("pad0", i32),
         ("wind", f64 * 3), ("kf_x", f64 * 6), ("kf_P", f32 * 4),
         ("on_delay", i32), ("on_len", i32), ("on_ring", (f32 * 4) * RING_CAP),
-        ("g_len", i32), ("g_ring", (f32 * 8) * RING_CAP),
+        ("g_len", i32), ("g_ring", (f64 * 8) * RING_CAP),
         ("T0", f32), ("base_cd", f32), ("transonic_peak", f32), ("ep_return", f32),
     ]
 

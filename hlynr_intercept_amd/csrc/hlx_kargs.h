@@ -34,7 +34,8 @@ enum : int {
     G_MISC,      // float4: T0, base_cd, transonic peak multiplier, pad       [domain randomisation only]
     N_GROUPS
 };
-constexpr int GROUND_RING_WORDS16 = 2;  // float4 {rel_pos xyz, quality}, float4 {rel_vel xyz, measurement-is-float64 flag}
+// ground ring slot: double2 {rel_pos x, y}, {double rel_pos z, float quality, float sample-was-a-detection}, float4 {rel_vel xyz, pad}
+constexpr int GROUND_RING_WORDS16 = 3;
 
 struct KCfg {
     uint32_t flags;
@@ -64,7 +65,7 @@ struct KArgs {
     float radius, on_rel, g_rel;  // curriculum scalars in force for this launch
     double half_beam;
     float4* arena;
-    float4* gring;  // [g_delay+1][2][N]
+    float4* gring;  // [g_delay+1][GROUND_RING_WORDS16][N]
     float4* oring;  // [o_cap][N]
     int32_t n;
     const float* actions;
@@ -76,8 +77,8 @@ struct KArgs {
     int32_t* done_idx;
     int32_t* done_cnt;  // [2], double-buffered by vec-step parity
     hlx_info_soa info;
-    const float* step_noise;
-    const float* reset_noise;
+    const double* step_noise;   // parity mode: slot-major [HLX_STEP_SLOTS][N] float64 unit draws (NULL = Philox)
+    const double* reset_noise;  // [HLX_RESET_SLOTS][N]
     const unsigned long long* t_dev;  // optional device-resident clock base (hipGraph replay)
     unsigned long long t_add;
     uint32_t seed_lo, seed_hi;

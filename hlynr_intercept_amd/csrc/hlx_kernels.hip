@@ -79,8 +79,8 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
         const bool noise_buf = a.step_noise != nullptr;
         const unsigned long long gid = (unsigned long long)(a.env_offset + i);
         Rng rng{uint2{a.seed_lo, a.seed_hi}, (uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)t, (uint32_t)(t >> 32)};
-        const float* SN = a.step_noise + i;   // slot-major [slot][N]
-        const float* RN = a.reset_noise + i;
+        const double* SN = a.step_noise + i;   // slot-major [slot][N] (float64: parity mode replays the reference's draws)
+        const double* RN = a.reset_noise + i;
 
         float reward = 0.f, distance = 0.f;
         bool terminated = false, truncated = false, intercepted = false, hit_target = false, fuze = false,
@@ -192,10 +192,10 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     sum = to_d3(v3(md.x, md.y, md.z + GRAV));
                 }
                 if (HAS(HLX_F_EVASION)) {                                           // :1103-1108 (float64)
-                    V3 z;
-                    if (noise_buf) z = v3(SN[0 * N], SN[1 * N], SN[2 * N]);
-                    else { float w_; rng.normals4(RS_EVASION, z.x, z.y, z.z, w_); }
-                    sum = d3(sum.x + (double)z.x * 2.0, sum.y + (double)z.y * 2.0, sum.z + (double)z.z * 2.0);
+                    D3 z;
+                    if (noise_buf) z = d3(SN[0 * N], SN[1 * N], SN[2 * N]);
+                    else { V3 zf; float w_; rng.normals4(RS_EVASION, zf.x, zf.y, zf.z, w_); z = to_d3(zf); }
+                    sum = d3(sum.x + z.x * 2.0, sum.y + z.y * 2.0, sum.z + z.z * 2.0);
                 }
                 if (HAS(HLX_F_VALIDATION)) sum = nan_guard(sum, 20.0);
                 mvel = v3((float)((double)mvel.x + sum.x * c.dt64), (float)((double)mvel.y + sum.y * c.dt64),
@@ -212,34 +212,33 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     ti = c.ti_mid * (1.0f - (walt / c.bl_height) * 0.7f);           // :343-346
                 } else { prof = c.bl_prof; ti = c.ti_high; }
                 V3 w = v3(c.base_wind[0] * prof, c.base_wind[1] * prof, c.base_wind[2] * prof);
-                V3 z; float gu;
-                if (noise_buf) { z = v3(SN[3 * N], SN[4 * N], SN[5 * N]); gu = SN[6 * N]; }
+                D3 z; double gu;
+                if (noise_buf) { z = d3(SN[3 * N], SN[4 * N], SN[5 * N]); gu = SN[6 * N]; }
                 else {
-                    float w_; rng.normals4(RS_WIND, z.x, z.y, z.z, w_);
-                    gu = u01(rng.raw(RS_STEP_U).w);
+                    V3 zf; float w_; rng.normals4(RS_WIND, zf.x, zf.y, zf.z, w_); z = to_d3(zf);
+                    gu = (double)u01(rng.raw(RS_STEP_U).w);
                 }
                 if (ti > 0.f) {                                                     // :370-378
                     double scale = (double)(ti * snorm3(w));
-                    w = v3((float)((double)w.x + (scale * (double)z.x) * c.turb_lp), (float)((double)w.y + (scale * (double)z.y) * c.turb_lp),
-                           (float)((double)w.z + (scale * (double)z.z) * c.turb_lp));
+                    w = v3((float)((double)w.x + (scale * z.x) * c.turb_lp), (float)((double)w.y + (scale * z.y) * c.turb_lp),
+                           (float)((double)w.z + (scale * z.z) * c.turb_lp));
                 }
-                if (gu < 0.001f) {                                                  // :381-385
-                    V3 g; float e;
-                    if (noise_buf) { g = v3(SN[7 * N], SN[8 * N], SN[9 * N]); e = SN[10 * N]; }
-                    else gust_draws(rng, g, e);
-                    D3 gd = to_d3(g);
-                    double gn = dnorm(gd) + 1e-6, gmag = c.gust_scale * (double)e;
+                if (gu < 0.001) {                                                   // :381-385
+                    D3 gd; double e;
+                    if (noise_buf) { gd = d3(SN[7 * N], SN[8 * N], SN[9 * N]); e = SN[10 * N]; }
+                    else { V3 g; float ef; gust_draws(rng, g, ef); gd = to_d3(g); e = (double)ef; }
+                    double gn = dnorm(gd) + 1e-6, gmag = c.gust_scale * e;
                     w = v3((float)((double)w.x + (gd.x / gn) * gmag), (float)((double)w.y + (gd.y / gn) * gmag),
                            (float)((double)w.z + (gd.z / gn) * gmag));
                 }
                 wind = to_d3(w);
             } else if (simple_wind) {                                               // :1127-1129
-                V3 z;
-                if (noise_buf) z = v3(SN[3 * N], SN[4 * N], SN[5 * N]);
-                else { float w_; rng.normals4(RS_WIND, z.x, z.y, z.z, w_); }
-                auto upd = [&](double w, float base, float zz) {
+                D3 z;
+                if (noise_buf) z = d3(SN[3 * N], SN[4 * N], SN[5 * N]);
+                else { V3 zf; float w_; rng.normals4(RS_WIND, zf.x, zf.y, zf.z, w_); z = to_d3(zf); }
+                auto upd = [&](double w, float base, double zz) {
                     double t1 = w64 ? 0.95 * w : (double)(0.95f * (float)w);
-                    return t1 + 0.05 * ((double)base + (double)zz * c.wind_var);
+                    return t1 + 0.05 * ((double)base + zz * c.wind_var);
                 };
                 wind = d3(upd(wind.x, c.base_wind[0], z.x), upd(wind.y, c.base_wind[1], z.y), upd(wind.z, c.base_wind[2], z.z));
             }
@@ -326,7 +325,9 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
         // pass 0: observation of the stepped state.  pass 1 (only if some lane of the wave finished):
         // finished lanes respawn (environment.py:353-603) and build their first observation.
         const int g_cap = c.g_delay + 1, o_cap = c.o_cap;
-        float4 on_sample = make_float4(0.f, 0.f, 0.f, 0.f), g_s0 = on_sample, g_s1 = on_sample;
+        float4 on_sample = make_float4(0.f, 0.f, 0.f, 0.f), g_s2 = on_sample;
+        D3 g_sp = d3(0., 0., 0.);          // ground ring sample: float64 measured rel_pos, float32 quality/flag, rel_vel
+        float g_sq = 0.f, g_sflag = 0.f;
         uint32_t det_bits = 0;
 #pragma unroll 1
         for (int pass = (MODE == 0 ? 0 : 1); pass < 2; ++pass) {
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     double u[10];
                     if (rbuf) {
 #pragma unroll
-                        for (int k = 0; k < 10; ++k) u[k] = (double)RN[k * N];
+                        for (int k = 0; k < 10; ++k) u[k] = RN[k * N];
                     } else {
                         uint4 x0 = rng.raw(RS_RESET_U0), x1 = rng.raw(RS_RESET_U1), x2 = rng.raw(RS_RESET_U2);
                         u[0] = u01(x0.x); u[1] = u01(x0.y); u[2] = u01(x0.z); u[3] = u01(x0.w);
@@ -396,15 +397,17 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     wind = d3((double)c.base_wind[0], (double)c.base_wind[1], (double)c.base_wind[2]); // :542
                     thrust_act = v3(0.f, 0.f, 0.f);                                 // :549
                     if (HAS(HLX_F_DOMAIN_RAND)) {                                   // :552-562, physics_randomizer.py
-                        float zt, zd, zm, zs;
+                        double zt, zd, zm, zs;
                         if (rbuf) { zt = RN[20 * N]; zd = RN[21 * N]; zm = RN[22 * N]; zs = RN[23 * N]; }
                         else {
                             // draws 1..4 of the 13 (the others never reach the path): temperature, drag, mach, delay
-                            float z0_; rng.normals4(RS_DR0, z0_, zt, zd, zm);
-                            float z1_, z2_, z3_; rng.normals4(RS_DR1, zs, z1_, z2_, z3_);
+                            float z0_, f1, f2, f3, f4, z1_, z2_, z3_;
+                            rng.normals4(RS_DR0, z0_, f1, f2, f3);
+                            rng.normals4(RS_DR1, f4, z1_, z2_, z3_);
+                            zt = f1; zd = f2; zm = f3; zs = f4;
                         }
-                        auto mult = [](double var, float z) { return fmin(fmax(1.0 + var * (double)z, 0.1), 3.0); };
-                        if (HAS(HLX_F_ATMOSPHERE)) T0 = (float)((double)T0 + c.dr_var[1] * (double)zt); // :258-261 (accumulates)
+                        auto mult = [](double var, double z) { return fmin(fmax(1.0 + var * z, 0.1), 3.0); };
+                        if (HAS(HLX_F_ATMOSPHERE)) T0 = (float)((double)T0 + c.dr_var[1] * zt); // :258-261 (accumulates)
                         if (HAS(HLX_F_MACH_DRAG)) {                                 // :270-280
                             dp.base_cd = (float)(0.3 * mult(c.dr_var[2], zd));
                             dp.peak = (float)(3.0 * mult(c.dr_var[3], zm));
@@ -422,17 +425,18 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
             }
             if (act) {
                 // ======================================================== core.py:511-691 radar detection
-                float n_on, n_g, n_dl;
-                V3 n_gp, n_gv;
+                float n_on, n_g;
+                double n_dl;
+                D3 n_gp, n_gv;
                 const bool from_buf = (pass == 0) ? noise_buf : (a.reset_noise != nullptr);
                 if (from_buf) {
-                    const float* B = (pass == 0) ? (SN + 11 * N) : (RN + 10 * N);
-                    n_on = B[0]; n_g = B[1 * N]; n_gp = v3(B[2 * N], B[3 * N], B[4 * N]);
-                    n_gv = v3(B[5 * N], B[6 * N], B[7 * N]); n_dl = B[8 * N];
+                    const double* B = (pass == 0) ? (SN + 11 * N) : (RN + 10 * N);
+                    n_on = (float)B[0]; n_g = (float)B[1 * N]; n_gp = d3(B[2 * N], B[3 * N], B[4 * N]);
+                    n_gv = d3(B[5 * N], B[6 * N], B[7 * N]); n_dl = B[8 * N];
                 } else {
                     uint4 x = rng.raw(pass == 0 ? RS_STEP_U : RS_RESET_OBS_U);
-                    n_on = u01(x.x); n_g = u01(x.y); n_dl = u01(x.z);
-                    n_gp = n_gv = v3(0.f, 0.f, 0.f);   // drawn below, only if the ground radar detects
+                    n_on = u01(x.x); n_g = u01(x.y); n_dl = (double)u01(x.z);
+                    n_gp = n_gv = d3(0., 0., 0.);   // drawn below, only if the ground radar detects
                 }
                 const V3 rel = mpos - ipos;
                 const float range = snorm3(rel);
@@ -460,7 +464,8 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                 }
                 // ---- ground radar (core.py:368-438)
                 bool g_det = false;
-                V3 g_pos = v3(0.f, 0.f, 0.f), g_vel = g_pos;
+                D3 g_pos = d3(0., 0., 0.);
+                V3 g_vel = v3(0.f, 0.f, 0.f);
                 float g_q = 0.f;
                 const V3 gp = v3(c.ground_pos[0], c.ground_pos[1], c.ground_pos[2]);
                 if (HAS(HLX_F_GROUND)) {
@@ -477,42 +482,47 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                         if (n_g > dpq) g_det = false;
                         else {
                             if (!from_buf) {
-                                float w0_, w1_;
-                                rng.normals4(pass == 0 ? RS_GPOS : RS_RESET_GPOS, n_gp.x, n_gp.y, n_gp.z, w0_);
-                                rng.normals4(pass == 0 ? RS_GVEL : RS_RESET_GVEL, n_gv.x, n_gv.y, n_gv.z, w1_);
+                                V3 p_, v_; float w0_, w1_;
+                                rng.normals4(pass == 0 ? RS_GPOS : RS_RESET_GPOS, p_.x, p_.y, p_.z, w0_);
+                                rng.normals4(pass == 0 ? RS_GVEL : RS_RESET_GVEL, v_.x, v_.y, v_.z, w1_);
+                                n_gp = to_d3(p_); n_gv = to_d3(v_);
                             }
-                            // :422-429 float64 measurement, held in float32 in the ring (quantisation ~1e-4 m
-                            // against 10 m of measurement noise; it does not accumulate in the filter)
-                            g_pos = v3((float)((double)rel.x + c.g_range_acc * (double)n_gp.x), (float)((double)rel.y + c.g_range_acc * (double)n_gp.y),
-                                       (float)((double)rel.z + c.g_range_acc * (double)n_gp.z));
+                            // :422-429 float64 measurement (kept float64 through the delay ring: the Kalman
+                            // velocity estimate is tiny while detections are continuous, so outputs such as the
+                            // lead-angle cosine are sensitive to 1e-4 m of measurement rounding)
+                            g_pos = d3((double)rel.x + c.g_range_acc * n_gp.x, (double)rel.y + c.g_range_acc * n_gp.y,
+                                       (double)rel.z + c.g_range_acc * n_gp.z);
                             V3 rv = mvel - ivel;
-                            g_vel = v3((float)((double)rv.x + c.g_vel_acc * (double)n_gv.x), (float)((double)rv.y + c.g_vel_acc * (double)n_gv.y),
-                                       (float)((double)rv.z + c.g_vel_acc * (double)n_gv.z));
+                            g_vel = v3((float)((double)rv.x + c.g_vel_acc * n_gv.x), (float)((double)rv.y + c.g_vel_acc * n_gv.y),
+                                       (float)((double)rv.z + c.g_vel_acc * n_gv.z));
                             g_q = dpq;
                         }
                     }
                 }
-                V3 d_gp = g_pos, d_gv = g_vel;
+                D3 d_gp64 = g_pos;
+                V3 d_gv = g_vel;
                 float d_gq = g_q;
                 bool d_g_det = g_det, d_g64 = g_det;    // d_g64: the delayed sample is a real (float64) measurement
                 if (HAS(HLX_F_GROUND) && c.g_delay > 0) {                           // :609-627 ground delay ring
-                    g_s0 = make_float4(g_pos.x, g_pos.y, g_pos.z, g_q);
-                    g_s1 = make_float4(g_vel.x, g_vel.y, g_vel.z, g_det ? 1.f : 0.f);
-                    d_gp = v3(0.f, 0.f, 0.f); d_gv = d_gp; d_gq = 0.f; d_g_det = false; d_g64 = false;
+                    g_sp = g_pos; g_sq = g_q; g_sflag = g_det ? 1.f : 0.f;
+                    g_s2 = make_float4(g_vel.x, g_vel.y, g_vel.z, 0.f);
+                    d_gp64 = d3(0., 0., 0.); d_gv = v3(0.f, 0.f, 0.f); d_gq = 0.f; d_g_det = false; d_g64 = false;
                     if (pass == 0 && steps >= c.g_delay) {
                         int slot = (int)((t + 1ull) % (unsigned long long)g_cap);   // == (t - g_delay) mod g_cap
-                        const float4* R = a.gring + ((size_t)slot * 2) * N + i;
-                        float4 s0 = R[0], s1 = R[N];
-                        d_gp = v3(s0.x, s0.y, s0.z); d_gq = s0.w; d_gv = v3(s1.x, s1.y, s1.z);
-                        d_g64 = s1.w != 0.f;
+                        const float4* R = a.gring + ((size_t)slot * GROUND_RING_WORDS16) * N + i;
+                        double2 s0 = *reinterpret_cast<const double2*>(R);
+                        float4 s1 = R[N], s2 = R[2 * N];
+                        d_gp64 = d3(s0.x, s0.y, __hiloint2double(__float_as_int(s1.y), __float_as_int(s1.x)));
+                        d_gq = s1.z; d_g64 = s1.w != 0.f; d_gv = v3(s2.x, s2.y, s2.z);
                         d_g_det = g_det;                                            // :626 CURRENT flag (reference quirk)
                     }
                 }
+                const V3 d_gp = to_v3(d_gp64);
                 // ---- datalink (core.py:440-474)
                 float datalink = 0.f;
                 if (HAS(HLX_F_GROUND)) {
                     float lr = snorm3(ipos - gp);
-                    if (!(lr > c.max_datalink) && !((double)n_dl < c.packet_loss)) {
+                    if (!(lr > c.max_datalink) && !(n_dl < c.packet_loss)) {
                         float x = lr / c.max_datalink;
                         float vr = divc(snorm3(ivel), 1.0 / 1000.0);
                         float dop = (0.3f < vr) ? (float)(1.0 - 0.3) : (1.0f - vr);
@@ -541,16 +551,16 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                         m64 = d_g64;
                         if (m64) {
                             double total = (double)(c.radar_quality + d_gq);
-                            z = d3(((double)(d_on.x * c.radar_quality) + (double)d_gp.x * (double)d_gq) / total,
-                                   ((double)(d_on.y * c.radar_quality) + (double)d_gp.y * (double)d_gq) / total,
-                                   ((double)(d_on.z * c.radar_quality) + (double)d_gp.z * (double)d_gq) / total);
+                            z = d3(((double)(d_on.x * c.radar_quality) + d_gp64.x * (double)d_gq) / total,
+                                   ((double)(d_on.y * c.radar_quality) + d_gp64.y * (double)d_gq) / total,
+                                   ((double)(d_on.z * c.radar_quality) + d_gp64.z * (double)d_gq) / total);
                         } else {   // stale zero sample: weight 0.0 (python float) -> float32 arithmetic
                             float total = (float)c.radar_quality64;
                             z = to_d3(v3((d_on.x * c.radar_quality) / total, (d_on.y * c.radar_quality) / total,
                                          (d_on.z * c.radar_quality) / total));
                         }
                     } else if (d_on_det) { m64 = false; z = to_d3(d_on); }
-                    else { m64 = d_g64; z = to_d3(d_gp); }
+                    else { m64 = d_g64; z = d_gp64; }
                     z = d3(rr((double)ipos.x + z.x, m64), rr((double)ipos.y + z.y, m64), rr((double)ipos.z + z.z, m64)); // :749
                     if (!kf_init) {                                                 // core.py:93-96
                         kxp = d3((double)(float)z.x, (double)(float)z.y, (double)(float)z.z);
@@ -586,8 +596,12 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                 // ---- observation vector: pure outputs, ordinary fast float32 from here on
                 const float inv_mr = 1.0f / c.max_range, inv_mv = 1.0f / c.max_velocity;
                 if (have_track) {                                                   // :778-906
-                    const V3 frp = to_v3(d3(kxp.x - (double)ipos.x, kxp.y - (double)ipos.y, kxp.z - (double)ipos.z));
-                    const V3 frv = to_v3(d3(kxv.x - (double)ivel.x, kxv.y - (double)ivel.y, kxv.z - (double)ivel.z));
+                    // filtered relative position / velocity in the Kalman state's dtype (:758-759,:767-768); the
+                    // target-velocity estimate frv + ivel (:861) cancels back to the (small) Kalman velocity, so it
+                    // is formed before anything is narrowed to float32
+                    const D3 frp64 = d3(rr(kxp.x - (double)ipos.x, kf_x64), rr(kxp.y - (double)ipos.y, kf_x64), rr(kxp.z - (double)ipos.z, kf_x64));
+                    const D3 frv64 = d3(rr(kxv.x - (double)ivel.x, kf_x64), rr(kxv.y - (double)ivel.y, kf_x64), rr(kxv.z - (double)ivel.z, kf_x64));
+                    const V3 frp = to_v3(frp64), frv = to_v3(frv64);
                     const float rrange = fnorm(frp);
                     const float closing = -fdot(frp, frv) / (rrange + 1e-6f);       // :786
                     if (HAS(HLX_F_OBS_LOS)) {                                       // :791-868
@@ -601,7 +615,8 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                         row[3] = clampf(fdot(rate, v) * 2.0f, -1.f, 1.f);
                         float ivm = fnorm(ivel);
                         row[4] = (ivm > 1e-6f) ? fdot(ivel, lu) / ivm : 0.f;        // :852-858
-                        V3 tv = frv + ivel;                                         // :861
+                        V3 tv = to_v3(d3(rr(frv64.x + (double)ivel.x, kf_x64), rr(frv64.y + (double)ivel.y, kf_x64),
+                                         rr(frv64.z + (double)ivel.z, kf_x64)));                // :861
                         float tvm = fnorm(tv);
                         row[5] = (tvm > 1e-6f) ? -fdot(tv, lu) / tvm : 0.f;
                         row[6] = clampf(ivm * inv_mv, 0.f, 1.f);                    // :924-925
@@ -698,8 +713,10 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
             if (HAS(HLX_F_DOMAIN_RAND)) A[G_MISC * N] = make_float4(T0, dp.base_cd, dp.peak, 0.f);
             if (c.o_delay > 0) a.oring[(size_t)(t % (unsigned long long)o_cap) * N + i] = on_sample;
             if (HAS(HLX_F_GROUND) && c.g_delay > 0) {
-                float4* R = a.gring + ((size_t)(t % (unsigned long long)g_cap) * 2) * N + i;
-                R[0] = g_s0; R[N] = g_s1;
+                float4* R = a.gring + ((size_t)(t % (unsigned long long)g_cap) * GROUND_RING_WORDS16) * N + i;
+                *reinterpret_cast<double2*>(R) = make_double2(g_sp.x, g_sp.y);
+                R[N] = make_float4(__int_as_float(__double2loint(g_sp.z)), __int_as_float(__double2hiint(g_sp.z)), g_sq, g_sflag);
+                R[2 * N] = g_s2;
             }
         }
         if (MODE == 0) {

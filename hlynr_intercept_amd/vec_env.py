@@ -327,7 +327,10 @@ class HlynrVecEnv:
 
     # ------------------------------------------------------------------ parity / checkpoint hooks
     def set_noise(self, step_noise=None, reset_noise=None):
-        """Parity mode: slot-major device tensors [20, N] / [32, N] replace the Philox draws (None restores)."""
+        """Parity mode: slot-major float64 device tensors [20, N] / [32, N] replace the Philox draws (None restores)."""
+        for x in (step_noise, reset_noise):
+            if x is not None and (x.dtype != self._torch.float64 or not x.is_contiguous()):
+                raise ValueError("noise tensors must be contiguous float64")
         self._noise = (step_noise, reset_noise)
         _lib.check(self._lib.hlx_set_noise(self._h, step_noise.data_ptr() if step_noise is not None else None,
                                            reset_noise.data_ptr() if reset_noise is not None else None))
@@ -336,8 +339,8 @@ class HlynrVecEnv:
         """The Philox draws of the next step (or, `for_reset=True`, of a reset issued now) as slot-major
         tensors ([20, N], [32, N])."""
         t = self._torch
-        sn = t.zeros((_lib.STEP_SLOTS, self.num_envs), device=self.device)
-        rn = t.zeros((_lib.RESET_SLOTS, self.num_envs), device=self.device)
+        sn = t.zeros((_lib.STEP_SLOTS, self.num_envs), device=self.device, dtype=t.float64)
+        rn = t.zeros((_lib.RESET_SLOTS, self.num_envs), device=self.device, dtype=t.float64)
         _lib.check(self._lib.hlx_fill_noise(self._h, sn.data_ptr(), rn.data_ptr(), 0 if for_reset else 1, self._stream()))
         return sn, rn
 

@@ -128,7 +128,8 @@ typedef struct hlx_env_state {
     int32_t on_delay, on_len;
     float on_ring[HLX_RING_CAP][4];     /* oldest -> newest : rel_pos xyz, detected(0/1) */
     int32_t g_len;
-    float g_ring[HLX_RING_CAP][8];      /* oldest -> newest : rel_pos xyz, quality, rel_vel xyz, sample-was-a-detection flag */
+    double g_ring[HLX_RING_CAP][8];     /* oldest -> newest : rel_pos xyz (float64 measurement), quality, rel_vel xyz,
+                                           sample-was-a-detection flag */
     float T0, base_cd, transonic_peak;  /* constants touched by domain randomisation */
     float ep_return;
 } hlx_env_state;
@@ -168,12 +169,14 @@ int hlx_set_global_step(hlx_env *env, int64_t global_step);
 int hlx_get_curriculum(hlx_env *env, double out[5]);
 
 /* Parity mode: take the random draws from caller-supplied DEVICE arrays instead of Philox.
- * step_noise [HLX_STEP_SLOTS][N], reset_noise [HLX_RESET_SLOTS][N] (slot-major).  NULL restores Philox. */
-int hlx_set_noise(hlx_env *env, const float *step_noise, const float *reset_noise);
+ * step_noise [HLX_STEP_SLOTS][N], reset_noise [HLX_RESET_SLOTS][N] (slot-major), FLOAT64 unit draws
+ * (the reference draws float64 variates; replaying them exactly needs all 53 bits).  NULL restores Philox. */
+int hlx_set_noise(hlx_env *env, const double *step_noise, const double *reset_noise);
 /* Write the Philox draws of vec-step clock (current + clock_offset) into slot-major device arrays
  * (every slot, whether or not it ends up being consumed): clock_offset = 1 -> what the NEXT hlx_step
- * (and its auto-resets) will draw; clock_offset = 0 -> what an hlx_reset issued now will draw. */
-int hlx_fill_noise(hlx_env *env, float *step_noise, float *reset_noise, int32_t clock_offset, void *stream);
+ * (and its auto-resets) will draw; clock_offset = 0 -> what an hlx_reset issued now will draw.
+ * Philox produces float32 variates; they are stored widened to float64. */
+int hlx_fill_noise(hlx_env *env, double *step_noise, double *reset_noise, int32_t clock_offset, void *stream);
 
 /* Logical state export / injection (host array of n_envs hlx_env_state).  Synchronises. */
 int hlx_get_state(hlx_env *env, hlx_env_state *host_out);

@@ -15,10 +15,10 @@ for name in sys.argv[1:]:
         env.set_training_step_count(fx["global_step_or_none"])
     dev = env.device
     T = len(fx["action"])
-    sn_all = torch.tensor(np.nan_to_num(fx["step_noise"], nan=0.5), dtype=torch.float32, device=dev)[:, :, None].contiguous()
-    rn0 = torch.tensor(np.nan_to_num(fx["reset_noise0"], nan=0.5), dtype=torch.float32, device=dev)[:, None].contiguous()
+    sn_all = torch.tensor(np.nan_to_num(fx["step_noise"], nan=0.5), dtype=torch.float64, device=dev)[:, :, None].contiguous()
+    rn0 = torch.tensor(np.nan_to_num(fx["reset_noise0"], nan=0.5), dtype=torch.float64, device=dev)[:, None].contiguous()
     if "reset_noise" in fx:
-        rn_all = torch.tensor(np.nan_to_num(fx["reset_noise"], nan=0.5), dtype=torch.float32, device=dev)[:, :, None].contiguous()
+        rn_all = torch.tensor(np.nan_to_num(fx["reset_noise"], nan=0.5), dtype=torch.float64, device=dev)[:, :, None].contiguous()
     actions = torch.tensor(fx["action"], dtype=torch.float32, device=dev)[:, None, :].contiguous()
     env.set_noise(sn_all[0], rn0)
     env.reset_torch()
