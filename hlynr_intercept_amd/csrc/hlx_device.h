@@ -57,7 +57,32 @@ DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); 
 // x / c with c a constant whose float64 reciprocal is `inv`
 DEV float divc(float x, double inv) { return (float)((double)x * inv); }
 DEV V3 divc(V3 a, double inv) { return V3{divc(a.x, inv), divc(a.y, inv), divc(a.z, inv)}; }
+// sin / cos of a small angle (|x| <= 0.35 rad: half of the largest per-step rotation, 20*sqrt(3) rad/s * dt)
+// to ~1e-15, i.e. the float32 rounding of the result equals that of a correctly rounded libm call except
+// with probability ~1e-7.  Taylor series in float64; contraction is fine here (only the value matters).
+DEV double sin_small(double x) {
+    const double x2 = x * x;
+    double p = __builtin_fma(x2, -1.0 / 1307674368000.0, 1.0 / 6227020800.0);
+    p = __builtin_fma(x2, p, -1.0 / 39916800.0);
+    p = __builtin_fma(x2, p, 1.0 / 362880.0);
+    p = __builtin_fma(x2, p, -1.0 / 5040.0);
+    p = __builtin_fma(x2, p, 1.0 / 120.0);
+    p = __builtin_fma(x2, p, -1.0 / 6.0);
+    return __builtin_fma(x * x2, p, x);
+}
+DEV double cos_small(double x) {
+    const double x2 = x * x;
+    double p = __builtin_fma(x2, 1.0 / 20922789888000.0, -1.0 / 87178291200.0);
+    p = __builtin_fma(x2, p, 1.0 / 479001600.0);
+    p = __builtin_fma(x2, p, -1.0 / 3628800.0);
+    p = __builtin_fma(x2, p, 1.0 / 40320.0);
+    p = __builtin_fma(x2, p, -1.0 / 720.0);
+    p = __builtin_fma(x2, p, 1.0 / 24.0);
+    p = __builtin_fma(x2, p, -0.5);
+    return __builtin_fma(x2, p, 1.0);
+}
 // fast (non-mirrored) helpers for pure outputs
+DEV float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 DEV float fdot(V3 a, V3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
 DEV float fnorm(V3 a) { return __builtin_sqrtf(fdot(a, a)); }
 
@@ -69,8 +94,9 @@ DEV uint4 philox4x32_10(uint4 c, uint2 k) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
-        uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+        // one 32x32->64 multiply (v_mad_u64_u32) per word instead of separate mul_hi / mul_lo
+        const uint64_t p0 = (uint64_t)M0 * (uint64_t)c.x, p1 = (uint64_t)M1 * (uint64_t)c.z;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         c = uint4{hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0};
         k.x += W0;
         k.y += W1;
@@ -186,11 +212,11 @@ DEV V3 forward_vec(Quat q) {   // core.py:1143-1152
 }
 DEV V3 right_vec(Quat q) {     // core.py:1155-1164
     V3 f = v3(1.f - 2.f * (q.y * q.y + q.z * q.z), 2.f * (q.x * q.y + q.w * q.z), 2.f * (q.x * q.z - q.w * q.y));
-    return f * (1.0f / (fnorm(f) + 1e-6f));
+    return f * __builtin_amdgcn_rcpf(fnorm(f) + 1e-6f);
 }
 DEV V3 up_vec(Quat q) {        // core.py:1167-1176
     V3 f = v3(2.f * (q.x * q.y - q.w * q.z), 1.f - 2.f * (q.x * q.x + q.z * q.z), 2.f * (q.y * q.z + q.w * q.x));
-    return f * (1.0f / (fnorm(f) + 1e-6f));
+    return f * __builtin_amdgcn_rcpf(fnorm(f) + 1e-6f);
 }
 DEV Quat quat_mul(Quat a, Quat b) {  // environment.py:1322-1331 (left-to-right float32 sums)
     return Quat{((a.w * b.w - a.x * b.x) - a.y * b.y) - a.z * b.z, ((a.w * b.x + a.x * b.w) + a.y * b.z) - a.z * b.y,

@@ -15,8 +15,9 @@ constexpr uint32_t KF_CODEGEN_MASK = HLX_F_ATMOSPHERE | HLX_F_MACH_DRAG | HLX_F_
                                      HLX_F_PROX_FUZE | HLX_F_GROUND | HLX_F_SPHERICAL | HLX_F_TOWARD_MISSILE |
                                      HLX_F_OBS_BODY | HLX_F_OBS_LOS;
 
-// State arena: 16-byte groups, struct-of-arrays: arena[group][env].  Every load/store of a group is
-// one 16-byte-per-lane, 1-KiB-per-wave coalesced access.
+// State arena: 16-byte groups, blocked struct-of-arrays: arena[env / 64][group][env % 64].  Every load/store
+// of a group is one 16-byte-per-lane, 1-KiB-per-wave coalesced access, and a wave's whole state is one
+// contiguous N_GROUPS KiB chunk.
 enum : int {
     G_IPOS = 0,  // float4: interceptor position xyz, fuel
     G_IVEL,      // float4: interceptor velocity xyz, prev_distance
@@ -37,31 +38,37 @@ enum : int {
 // ground ring slot: double2 {rel_pos x, y}, {double rel_pos z, float quality, float sample-was-a-detection}, float4 {rel_vel xyz, pad}
 constexpr int GROUND_RING_WORDS16 = 3;
 
+// Per-step ("hot") constants: ride in the kernel-argument block and end up in SGPRs.
 struct KCfg {
     uint32_t flags;
     int32_t max_steps, g_delay, o_delay, o_cap;
     float dt;                 // F(dt)
     double dt64, inv_dtf;     // dt ; 1 / (double)F(dt)
-    float max_range, max_velocity;
+    float max_range, max_velocity, inv_max_range, inv_max_velocity;
     float target[3];
-    double mis_lo[3], mis_span[3], mis_radius[2], mis_az[2], mis_el[2], mis_speed[2];
-    double int_lo[3], int_span[3], ivel_lo[3], ivel_span[3], int_speed[2];
     float subsonic, supersonic, mach_span, peak, cd_super;
     double super_mult;
     float base_wind[3];
     double wind_var;
     float bl_height, bl_prof, ti_low, ti_mid, ti_high;
     double turb_lp, gust_scale, inv_tau;
-    double dr_var[5];
     float kill_radius, radar_quality, radar_range;
     double radar_quality64;
     float ground_pos[3], g_max_range, g_base_q, max_datalink, weather;
     double g_min_elev, g_max_elev, g_range_acc, g_vel_acc, packet_loss;
     float q11, q12, q22;      // Kalman process noise (core.py:34-42, q = 5^2)
 };
+// Spawn / domain-randomisation ("cold") constants: only finished environments read them, so they live
+// in device memory behind a pointer instead of occupying ~90 SGPRs of every wave.
+struct KCold {
+    double mis_lo[3], mis_span[3], mis_radius[2], mis_az[2], mis_el[2], mis_speed[2];
+    double int_lo[3], int_span[3], ivel_lo[3], ivel_span[3], int_speed[2];
+    double dr_var[5];
+};
 
 struct KArgs {
     KCfg c;
+    const KCold* cold;
     float radius, on_rel, g_rel;  // curriculum scalars in force for this launch
     double half_beam;
     float4* arena;

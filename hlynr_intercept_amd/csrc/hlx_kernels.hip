@@ -49,15 +49,17 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
 
     if (live) {
         const size_t N = (size_t)n;
-        float4* A = a.arena + i;
-        double2* AD = reinterpret_cast<double2*>(a.arena) + i;
+        // arena layout: [workgroup][group][64 lanes] of 16-byte words -> one contiguous ~11 KiB chunk per wave,
+        // group offsets are compile-time constants (no per-group 64-bit address arithmetic in SGPRs)
+        float4* A = a.arena + (size_t)blockIdx.x * (N_GROUPS * 64) + lane;
+        double2* AD = reinterpret_cast<double2*>(A);
         // ------------------------------------------------------------------ load state
-        float4 g_ipos = A[G_IPOS * N], g_ivel = A[G_IVEL * N], g_quat = A[G_QUAT * N], g_mpos = A[G_MPOS * N];
-        float4 g_mvel = A[G_MVEL * N], g_w1 = A[G_W1 * N], g_kfp = A[G_KFP * N];
-        double2 g_w0 = AD[G_W0 * N], g_kf0 = AD[G_KF0 * N], g_kf1 = AD[G_KF1 * N], g_kf2 = AD[G_KF2 * N];
+        float4 g_ipos = A[G_IPOS * 64], g_ivel = A[G_IVEL * 64], g_quat = A[G_QUAT * 64], g_mpos = A[G_MPOS * 64];
+        float4 g_mvel = A[G_MVEL * 64], g_w1 = A[G_W1 * 64], g_kfp = A[G_KFP * 64];
+        double2 g_w0 = AD[G_W0 * 64], g_kf0 = AD[G_KF0 * 64], g_kf1 = AD[G_KF1 * 64], g_kf2 = AD[G_KF2 * 64];
         float4 g_thr = make_float4(0.f, 0.f, 0.f, 0.f), g_misc = make_float4(288.15f, 0.3f, c.peak, 0.f);
-        if (HAS(HLX_F_THRUST_LAG)) g_thr = A[G_THRUST * N];
-        if (HAS(HLX_F_DOMAIN_RAND)) g_misc = A[G_MISC * N];
+        if (HAS(HLX_F_THRUST_LAG)) g_thr = A[G_THRUST * 64];
+        if (HAS(HLX_F_DOMAIN_RAND)) g_misc = A[G_MISC * 64];
 
         V3 ipos = v3(g_ipos.x, g_ipos.y, g_ipos.z), ivel = v3(g_ivel.x, g_ivel.y, g_ivel.z);
         Quat q = Quat{g_quat.x, g_quat.y, g_quat.z, g_quat.w};
@@ -133,7 +135,9 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                 else {                                                              // :920-921
                     double c1 = HAS(HLX_F_ATMOSPHERE) ? (double)(-0.15f * rho) : (-0.5 * 0.3 * 1.225);
                     double c2 = c1 * dnorm(va);
-                    dacc = d3((c2 * va.x) / 500.0, (c2 * va.y) / 500.0, (c2 * va.z) / 500.0);
+                    // (c2*v)/mass in float64: the reciprocal form differs by <= 1 ulp(f64), invisible after the
+                    // float32 rounding of the velocity except with probability ~1e-9
+                    dacc = d3((c2 * va.x) * (1.0 / 500.0), (c2 * va.y) * (1.0 / 500.0), (c2 * va.z) * (1.0 / 500.0));
                 }
                 D3 acc = d3((double)tacc.x + dacc.x, (double)tacc.y + dacc.y, ((double)tacc.z + dacc.z) + (double)GRAV); // :924
                 if (HAS(HLX_F_VALIDATION)) acc = nan_guard(acc, 50.0);
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                 float angle = wn * c.dt;
                 if (angle > 1e-6f) {
                     float half = angle * 0.5f;                                      // angle / 2 (exact)
-                    float ch = (float)cos((double)half), sh = (float)sin((double)half);
+                    float ch = (float)cos_small((double)half), sh = (float)sin_small((double)half);
                     Quat r = quat_mul(Quat{ch, (ang.x / wn) * sh, (ang.y / wn) * sh, (ang.z / wn) * sh}, q);
                     float nq = sqrtf((float)((((double)(r.w * r.w) + (double)(r.x * r.x)) + (double)(r.y * r.y)) + (double)(r.z * r.z)));
                     q = Quat{r.w / nq, r.x / nq, r.y / nq, r.z / nq};
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     else {
                         double c1 = HAS(HLX_F_ATMOSPHERE) ? (double)(-0.15f * mrho) : (-0.5 * 0.3 * 1.225);
                         double c2 = c1 * dnorm(va);
-                        md = d3((c2 * va.x) / 1000.0, (c2 * va.y) / 1000.0, (c2 * va.z) / 1000.0);
+                        md = d3((c2 * va.x) * (1.0 / 1000.0), (c2 * va.y) * (1.0 / 1000.0), (c2 * va.z) * (1.0 / 1000.0));
                     }
                     sum = d3(md.x, md.y, md.z + (double)GRAV);
                 } else {
@@ -345,6 +349,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                         if (a.info.episode_length) a.info.episode_length[i] = steps;
                     }
                     // ---------------- spawn (environment.py:375-567): float64 draws cast to float32
+                    const KCold& k = *a.cold;
                     const bool rbuf = a.reset_noise != nullptr;
                     double u[10];
                     if (rbuf) {
@@ -359,28 +364,28 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     const V3 tp = v3(c.target[0], c.target[1], c.target[2]);
                     if (HAS(HLX_F_SPHERICAL)) {                                     // :390-406
                         const double PI = 3.141592653589793;
-                        double radius = c.mis_radius[0] + c.mis_radius[1] * u[0];
-                        double az = ((c.mis_az[0] + c.mis_az[1] * u[1]) * PI) / 180.0;
-                        double el = ((c.mis_el[0] + c.mis_el[1] * u[2]) * PI) / 180.0;
+                        double radius = k.mis_radius[0] + k.mis_radius[1] * u[0];
+                        double az = ((k.mis_az[0] + k.mis_az[1] * u[1]) * PI) / 180.0;
+                        double el = ((k.mis_el[0] + k.mis_el[1] * u[2]) * PI) / 180.0;
                         mpos = v3((float)((double)tp.x + (radius * cos(el)) * cos(az)), (float)((double)tp.y + (radius * cos(el)) * sin(az)),
                                   (float)((double)tp.z + radius * sin(el)));
                     } else {                                                        // :409
-                        mpos = v3((float)(c.mis_lo[0] + c.mis_span[0] * u[0]), (float)(c.mis_lo[1] + c.mis_span[1] * u[1]),
-                                  (float)(c.mis_lo[2] + c.mis_span[2] * u[2]));
+                        mpos = v3((float)(k.mis_lo[0] + k.mis_span[0] * u[0]), (float)(k.mis_lo[1] + k.mis_span[1] * u[1]),
+                                  (float)(k.mis_lo[2] + k.mis_span[2] * u[2]));
                     }
-                    float speed = (float)(c.mis_speed[0] + c.mis_speed[1] * u[3]);  // :415
+                    float speed = (float)(k.mis_speed[0] + k.mis_speed[1] * u[3]);  // :415
                     V3 tt = tp - mpos;
                     float ttd = snorm3(tt);
                     mvel = (ttd > 1e-6f) ? (tt / ttd) * speed : v3(0.f, 0.f, 0.f);  // :418-423
-                    ipos = v3((float)(c.int_lo[0] + c.int_span[0] * u[4]), (float)(c.int_lo[1] + c.int_span[1] * u[5]),
-                              (float)(c.int_lo[2] + c.int_span[2] * u[6]));         // :445
+                    ipos = v3((float)(k.int_lo[0] + k.int_span[0] * u[4]), (float)(k.int_lo[1] + k.int_span[1] * u[5]),
+                              (float)(k.int_lo[2] + k.int_span[2] * u[6]));         // :445
                     V3 rel0 = mpos - ipos;
                     float reld = snorm3(rel0);
                     if (HAS(HLX_F_TOWARD_MISSILE) && reld > 1e-6f)                  // :452-462
-                        ivel = (rel0 / reld) * (float)(c.int_speed[0] + c.int_speed[1] * u[7]);
+                        ivel = (rel0 / reld) * (float)(k.int_speed[0] + k.int_speed[1] * u[7]);
                     else                                                            // :467
-                        ivel = v3((float)(c.ivel_lo[0] + c.ivel_span[0] * u[7]), (float)(c.ivel_lo[1] + c.ivel_span[1] * u[8]),
-                                  (float)(c.ivel_lo[2] + c.ivel_span[2] * u[9]));
+                        ivel = v3((float)(k.ivel_lo[0] + k.ivel_span[0] * u[7]), (float)(k.ivel_lo[1] + k.ivel_span[1] * u[8]),
+                                  (float)(k.ivel_lo[2] + k.ivel_span[2] * u[9]));
                     q = Quat{1.f, 0.f, 0.f, 0.f};                                   // :489-530 rotate +Z onto the LOS (float64)
                     if (reld > 1e-6f) {
                         V3 fd = rel0 / reld;
@@ -407,13 +412,13 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                             zt = f1; zd = f2; zm = f3; zs = f4;
                         }
                         auto mult = [](double var, double z) { return fmin(fmax(1.0 + var * z, 0.1), 3.0); };
-                        if (HAS(HLX_F_ATMOSPHERE)) T0 = (float)((double)T0 + c.dr_var[1] * zt); // :258-261 (accumulates)
+                        if (HAS(HLX_F_ATMOSPHERE)) T0 = (float)((double)T0 + k.dr_var[1] * zt); // :258-261 (accumulates)
                         if (HAS(HLX_F_MACH_DRAG)) {                                 // :270-280
-                            dp.base_cd = (float)(0.3 * mult(c.dr_var[2], zd));
-                            dp.peak = (float)(3.0 * mult(c.dr_var[3], zm));
+                            dp.base_cd = (float)(0.3 * mult(k.dr_var[2], zd));
+                            dp.peak = (float)(3.0 * mult(k.dr_var[3], zm));
                         }
                         if (c.o_delay > 0)                                          // :289-297
-                            on_delay = min(10, max(1, (int)(3.0 * mult(c.dr_var[4], zs))));
+                            on_delay = min(10, max(1, (int)(3.0 * mult(k.dr_var[4], zs))));
                     }
                     steps = 0; ep_return = 0.f;                                     // :565-566
                     kf_init = false; kf_x64 = false;                                // core.py:65-69
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                 else if (!d_g_det) fusion = (float)(c.radar_quality64 * 0.5);
                 else if (!d_on_det) fusion = d_gq * 0.6f;
                 else {
-                    float agree = 1.0f - fminf(fnorm(d_on - d_gp) / 200.f, 1.0f);
+                    float agree = 1.0f - fminf(fnorm(d_on - d_gp) * 0.005f, 1.0f);
                     fusion = clampf((float)(0.35 * c.radar_quality64) + 0.50f * d_gq + 0.15f * agree, 0.f, 1.f);
                 }
                 if (pass == 0) det_bits = (d_on_det ? 32u : 0u) | (d_g_det ? 64u : 0u);
@@ -550,10 +555,10 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     if (d_on_det && d_g_det) {
                         m64 = d_g64;
                         if (m64) {
-                            double total = (double)(c.radar_quality + d_gq);
-                            z = d3(((double)(d_on.x * c.radar_quality) + d_gp64.x * (double)d_gq) / total,
-                                   ((double)(d_on.y * c.radar_quality) + d_gp64.y * (double)d_gq) / total,
-                                   ((double)(d_on.z * c.radar_quality) + d_gp64.z * (double)d_gq) / total);
+                            const double itot = 1.0 / (double)(c.radar_quality + d_gq);   // one float64 reciprocal for 3 quotients
+                            z = d3(((double)(d_on.x * c.radar_quality) + d_gp64.x * (double)d_gq) * itot,
+                                   ((double)(d_on.y * c.radar_quality) + d_gp64.y * (double)d_gq) * itot,
+                                   ((double)(d_on.z * c.radar_quality) + d_gp64.z * (double)d_gq) * itot);
                         } else {   // stale zero sample: weight 0.0 (python float) -> float32 arithmetic
                             float total = (float)c.radar_quality64;
                             z = to_d3(v3((d_on.x * c.radar_quality) / total, (d_on.y * c.radar_quality) / total,
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     have_track = kf_init;
                 }
                 // ---- observation vector: pure outputs, ordinary fast float32 from here on
-                const float inv_mr = 1.0f / c.max_range, inv_mv = 1.0f / c.max_velocity;
+                const float inv_mr = c.inv_max_range, inv_mv = c.inv_max_velocity;
                 if (have_track) {                                                   // :778-906
                     // filtered relative position / velocity in the Kalman state's dtype (:758-759,:767-768); the
                     // target-velocity estimate frv + ivel (:861) cancels back to the (small) Kalman velocity, so it
@@ -603,22 +608,22 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     const D3 frv64 = d3(rr(kxv.x - (double)ivel.x, kf_x64), rr(kxv.y - (double)ivel.y, kf_x64), rr(kxv.z - (double)ivel.z, kf_x64));
                     const V3 frp = to_v3(frp64), frv = to_v3(frv64);
                     const float rrange = fnorm(frp);
-                    const float closing = -fdot(frp, frv) / (rrange + 1e-6f);       // :786
+                    const float closing = -fdiv(fdot(frp, frv), rrange + 1e-6f);    // :786
                     if (HAS(HLX_F_OBS_LOS)) {                                       // :791-868
                         row[0] = clampf(rrange * inv_mr, 0.f, 1.f);
                         row[1] = clampf(closing * inv_mv, -1.f, 1.f);
-                        V3 lu = (rrange > 1e-6f) ? frp * (1.0f / rrange) : v3(1.f, 0.f, 0.f);
-                        V3 rate = (frv - lu * closing) * (1.0f / (rrange + 1e-6f)); // :810-811
+                        V3 lu = (rrange > 1e-6f) ? frp * __builtin_amdgcn_rcpf(rrange) : v3(1.f, 0.f, 0.f);
+                        V3 rate = (frv - lu * closing) * __builtin_amdgcn_rcpf(rrange + 1e-6f); // :810-811
                         V3 h, v;
                         los_basis(lu, h, v);
                         row[2] = clampf(fdot(rate, h) * 2.0f, -1.f, 1.f);           // :844-845 (/0.5)
                         row[3] = clampf(fdot(rate, v) * 2.0f, -1.f, 1.f);
                         float ivm = fnorm(ivel);
-                        row[4] = (ivm > 1e-6f) ? fdot(ivel, lu) / ivm : 0.f;        // :852-858
+                        row[4] = (ivm > 1e-6f) ? fdiv(fdot(ivel, lu), ivm) : 0.f;    // :852-858
                         V3 tv = to_v3(d3(rr(frv64.x + (double)ivel.x, kf_x64), rr(frv64.y + (double)ivel.y, kf_x64),
                                          rr(frv64.z + (double)ivel.z, kf_x64)));                // :861
                         float tvm = fnorm(tv);
-                        row[5] = (tvm > 1e-6f) ? -fdot(tv, lu) / tvm : 0.f;
+                        row[5] = (tvm > 1e-6f) ? -fdiv(fdot(tv, lu), tvm) : 0.f;
                         row[6] = clampf(ivm * inv_mv, 0.f, 1.f);                    // :924-925
                         row[7] = clampf(fdot(ivel, h) * inv_mv, -1.f, 1.f);         // :948-953
                         row[8] = clampf(fdot(ivel, v) * inv_mv, -1.f, 1.f);
@@ -635,12 +640,12 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                         row[2] = clampf(frp.z * inv_mr, -1.f, 1.f); row[3] = clampf(frv.x * inv_mv, -1.f, 1.f);
                         row[4] = clampf(frv.y * inv_mv, -1.f, 1.f); row[5] = clampf(frv.z * inv_mv, -1.f, 1.f);
                     }
-                    row[13] = (closing > 0.f) ? clampf(1.0f - (rrange / closing) * 0.01f, -1.f, 1.f) : -1.f; // :885-889
+                    row[13] = (closing > 0.f) ? clampf(1.0f - fdiv(rrange, closing) * 0.01f, -1.f, 1.f) : -1.f; // :885-889
                     float tq = clampf(1.0f - ((p_pp + p_pp) + p_pp) * 1e-4f, 0.f, 1.f); // :892-893 trace of 3 equal blocks
                     if (d_on_det) tq *= c.radar_quality;                            // :894-895
                     row[14] = tq;
                     row[15] = clampf(closing * inv_mv, -1.f, 1.f);                  // :899
-                    row[16] = (rrange > 1e-6f) ? fdot(fwd, frp) / rrange : 1.0f;    // :902-906
+                    row[16] = (rrange > 1e-6f) ? fdiv(fdot(fwd, frp), rrange) : 1.0f; // :902-906
                 } else {                                                            // :907-917
 #pragma unroll
                     for (int k = 0; k < 6; ++k) row[k] = -2.0f;
@@ -667,10 +672,10 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                 if (d_g_det && datalink > 0.1f) {                                   // :980-1018
                     if (HAS(HLX_F_OBS_LOS)) {
                         float gr = fnorm(d_gp);
-                        float gc = -fdot(d_gp, d_gv) / (gr + 1e-6f);
+                        float gc = -fdiv(fdot(d_gp, d_gv), gr + 1e-6f);
                         row[17] = clampf(gr * inv_mr, 0.f, 1.f);
                         row[18] = clampf(gc * inv_mv, -1.f, 1.f);
-                        row[19] = (gr > 1e-6f) ? clampf(fnorm(d_gv - d_gp * (gc / gr)) / gr * 2.0f, 0.f, 1.f) : 0.f;
+                        row[19] = (gr > 1e-6f) ? clampf(fdiv(fnorm(d_gv - d_gp * fdiv(gc, gr)), gr) * 2.0f, 0.f, 1.f) : 0.f;
                         row[20] = 0.f; row[21] = 0.f; row[22] = 0.f;
                     } else if (HAS(HLX_F_OBS_BODY)) {
                         V3 r = right_vec(q), up = up_vec(q);
@@ -697,20 +702,20 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
         if (MODE == 0 || done) {
             packed = (uint32_t)steps | ((uint32_t)worsening << 13) | ((uint32_t)crossed << 25) |
                      ((uint32_t)kf_init << 26) | ((uint32_t)kf_x64 << 27) | ((uint32_t)on_delay << 28);
-            A[G_IPOS * N] = make_float4(ipos.x, ipos.y, ipos.z, fuel);
-            A[G_IVEL * N] = make_float4(ivel.x, ivel.y, ivel.z, prev_distance);
-            A[G_QUAT * N] = make_float4(q.w, q.x, q.y, q.z);
-            A[G_MPOS * N] = make_float4(mpos.x, mpos.y, mpos.z, min_distance);
-            A[G_MVEL * N] = make_float4(mvel.x, mvel.y, mvel.z, last_distance);
-            AD[G_W0 * N] = make_double2(wind.x, wind.y);
-            A[G_W1 * N] = make_float4(__int_as_float(__double2loint(wind.z)), __int_as_float(__double2hiint(wind.z)),
+            A[G_IPOS * 64] = make_float4(ipos.x, ipos.y, ipos.z, fuel);
+            A[G_IVEL * 64] = make_float4(ivel.x, ivel.y, ivel.z, prev_distance);
+            A[G_QUAT * 64] = make_float4(q.w, q.x, q.y, q.z);
+            A[G_MPOS * 64] = make_float4(mpos.x, mpos.y, mpos.z, min_distance);
+            A[G_MVEL * 64] = make_float4(mvel.x, mvel.y, mvel.z, last_distance);
+            AD[G_W0 * 64] = make_double2(wind.x, wind.y);
+            A[G_W1 * 64] = make_float4(__int_as_float(__double2loint(wind.z)), __int_as_float(__double2hiint(wind.z)),
                                       __uint_as_float(packed), ep_return);
-            AD[G_KF0 * N] = make_double2(kxp.x, kxp.y);
-            AD[G_KF1 * N] = make_double2(kxp.z, kxv.x);
-            AD[G_KF2 * N] = make_double2(kxv.y, kxv.z);
-            A[G_KFP * N] = make_float4(p_pp, p_pv, p_vp, p_vv);
-            if (HAS(HLX_F_THRUST_LAG)) A[G_THRUST * N] = make_float4(thrust_act.x, thrust_act.y, thrust_act.z, 0.f);
-            if (HAS(HLX_F_DOMAIN_RAND)) A[G_MISC * N] = make_float4(T0, dp.base_cd, dp.peak, 0.f);
+            AD[G_KF0 * 64] = make_double2(kxp.x, kxp.y);
+            AD[G_KF1 * 64] = make_double2(kxp.z, kxv.x);
+            AD[G_KF2 * 64] = make_double2(kxv.y, kxv.z);
+            A[G_KFP * 64] = make_float4(p_pp, p_pv, p_vp, p_vv);
+            if (HAS(HLX_F_THRUST_LAG)) A[G_THRUST * 64] = make_float4(thrust_act.x, thrust_act.y, thrust_act.z, 0.f);
+            if (HAS(HLX_F_DOMAIN_RAND)) A[G_MISC * 64] = make_float4(T0, dp.base_cd, dp.peak, 0.f);
             if (c.o_delay > 0) a.oring[(size_t)(t % (unsigned long long)o_cap) * N + i] = on_sample;
             if (HAS(HLX_F_GROUND) && c.g_delay > 0) {
                 float4* R = a.gring + ((size_t)(t % (unsigned long long)g_cap) * GROUND_RING_WORDS16) * N + i;
