@@ -34,7 +34,9 @@ namespace {
 
 DEV double rr(double x, bool is64) { return is64 ? x : (double)(float)x; }
 
-template <uint32_t SPEC, int MODE /*0 = step, 1 = reset-only*/>
+// NOISE = parity-mode instantiation that can take its random draws from caller-supplied float64 buffers;
+// the production instantiation (NOISE = false) contains no trace of that path.
+template <uint32_t SPEC, int MODE /*0 = step, 1 = reset-only*/, bool NOISE>
 __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
     __shared__ __attribute__((aligned(16))) float tile[64 * HLX_OBS_DIM];
     const uint32_t FL = (SPEC & KF_DYNAMIC) ? a.c.flags : SPEC;
@@ -53,13 +55,27 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
         // group offsets are compile-time constants (no per-group 64-bit address arithmetic in SGPRs)
         float4* A = a.arena + (size_t)blockIdx.x * (N_GROUPS * 64) + lane;
         double2* AD = reinterpret_cast<double2*>(A);
-        // ------------------------------------------------------------------ load state
+        // ------------------------------------------------------------------ issue every load up front
+        // (state groups, action row, the delayed ground-ring sample whose slot depends only on the global
+        // clock); the Philox draws below do not depend on them and run while the loads are in flight.
         float4 g_ipos = A[G_IPOS * 64], g_ivel = A[G_IVEL * 64], g_quat = A[G_QUAT * 64], g_mpos = A[G_MPOS * 64];
         float4 g_mvel = A[G_MVEL * 64], g_w1 = A[G_W1 * 64], g_kfp = A[G_KFP * 64];
         double2 g_w0 = AD[G_W0 * 64], g_kf0 = AD[G_KF0 * 64], g_kf1 = AD[G_KF1 * 64], g_kf2 = AD[G_KF2 * 64];
         float4 g_thr = make_float4(0.f, 0.f, 0.f, 0.f), g_misc = make_float4(288.15f, 0.3f, c.peak, 0.f);
         if (HAS(HLX_F_THRUST_LAG)) g_thr = A[G_THRUST * 64];
         if (HAS(HLX_F_DOMAIN_RAND)) g_misc = A[G_MISC * 64];
+        float2 a01 = make_float2(0.f, 0.f), a23 = a01, a45 = a01;
+        double2 gr0 = make_double2(0., 0.);
+        float4 gr1 = make_float4(0.f, 0.f, 0.f, 0.f), gr2 = gr1;
+        if (MODE == 0) {
+            const float2* ap = reinterpret_cast<const float2*>(a.actions + (size_t)i * HLX_ACT_DIM);
+            a01 = ap[0]; a23 = ap[1]; a45 = ap[2];
+            if (HAS(HLX_F_GROUND) && c.g_delay > 0) {
+                const int slot = (int)((t + 1ull) % (unsigned long long)(c.g_delay + 1));   // == (t - g_delay) mod cap
+                const float4* R = a.gring + ((size_t)slot * GROUND_RING_WORDS16) * N + i;
+                gr0 = *reinterpret_cast<const double2*>(R); gr1 = R[N]; gr2 = R[2 * N];
+            }
+        }
 
         V3 ipos = v3(g_ipos.x, g_ipos.y, g_ipos.z), ivel = v3(g_ivel.x, g_ivel.y, g_ivel.z);
         Quat q = Quat{g_quat.x, g_quat.y, g_quat.z, g_quat.w};
@@ -78,11 +94,36 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
         DragParams dp{c.subsonic, c.supersonic, c.mach_span, g_misc.z, g_misc.y, c.cd_super};
         if (HAS(HLX_F_DOMAIN_RAND)) dp.cd_super = (float)((double)dp.base_cd * c.super_mult);
 
-        const bool noise_buf = a.step_noise != nullptr;
+        const bool noise_buf = NOISE && a.step_noise != nullptr;
+        const bool rnoise_buf = NOISE && a.reset_noise != nullptr;
         const unsigned long long gid = (unsigned long long)(a.env_offset + i);
         Rng rng{uint2{a.seed_lo, a.seed_hi}, (uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)t, (uint32_t)(t >> 32)};
         const double* SN = a.step_noise + i;   // slot-major [slot][N] (float64: parity mode replays the reference's draws)
         const double* RN = a.reset_noise + i;
+
+        // ------------------------------------------------------------------ this step's random draws
+        // (five independent Philox chains in one straight-line block: instruction-level parallelism for
+        // the lone wave of this SIMD, and it overlaps the state loads issued above)
+        D3 z_ev = d3(0., 0., 0.), z_wind = z_ev, z_gp = z_ev, z_gv = z_ev;
+        float u_on = 0.f, u_g = 0.f;
+        double u_dl = 0., u_gust = 1.;
+        if (MODE == 0) {
+            if (noise_buf) {
+                z_ev = d3(SN[0 * N], SN[1 * N], SN[2 * N]); z_wind = d3(SN[3 * N], SN[4 * N], SN[5 * N]); u_gust = SN[6 * N];
+                u_on = (float)SN[11 * N]; u_g = (float)SN[12 * N];
+                z_gp = d3(SN[13 * N], SN[14 * N], SN[15 * N]); z_gv = d3(SN[16 * N], SN[17 * N], SN[18 * N]); u_dl = SN[19 * N];
+            } else {
+                V3 f; float w_;
+                if (HAS(HLX_F_EVASION)) { rng.normals4(RS_EVASION, f.x, f.y, f.z, w_); z_ev = to_d3(f); }
+                if (HAS(HLX_F_ENH_WIND) || c.wind_var > 0.0) { rng.normals4(RS_WIND, f.x, f.y, f.z, w_); z_wind = to_d3(f); }
+                const uint4 x = rng.raw(RS_STEP_U);
+                u_on = u01(x.x); u_g = u01(x.y); u_dl = (double)u01(x.z); u_gust = (double)u01(x.w);
+                if (HAS(HLX_F_GROUND)) {
+                    rng.normals4(RS_GPOS, f.x, f.y, f.z, w_); z_gp = to_d3(f);
+                    rng.normals4(RS_GVEL, f.x, f.y, f.z, w_); z_gv = to_d3(f);
+                }
+            }
+        }
 
         float reward = 0.f, distance = 0.f;
         bool terminated = false, truncated = false, intercepted = false, hit_target = false, fuze = false,
@@ -90,8 +131,6 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
 
         if (MODE == 0) {
             // -------------------------------------------------------------- action (environment.py:605-625)
-            const float2* ap = reinterpret_cast<const float2*>(a.actions + (size_t)i * HLX_ACT_DIM);
-            float2 a01 = ap[0], a23 = ap[1], a45 = ap[2];
             V3 at = v3(a01.x, a01.y, a23.x), aw = v3(a23.y, a45.x, a45.y);
             const float los_a0 = at.x;
             steps += 1;                                                             // :607
@@ -195,12 +234,8 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     }
                     sum = to_d3(v3(md.x, md.y, md.z + GRAV));
                 }
-                if (HAS(HLX_F_EVASION)) {                                           // :1103-1108 (float64)
-                    D3 z;
-                    if (noise_buf) z = d3(SN[0 * N], SN[1 * N], SN[2 * N]);
-                    else { V3 zf; float w_; rng.normals4(RS_EVASION, zf.x, zf.y, zf.z, w_); z = to_d3(zf); }
-                    sum = d3(sum.x + z.x * 2.0, sum.y + z.y * 2.0, sum.z + z.z * 2.0);
-                }
+                if (HAS(HLX_F_EVASION))                                             // :1103-1108 (float64)
+                    sum = d3(sum.x + z_ev.x * 2.0, sum.y + z_ev.y * 2.0, sum.z + z_ev.z * 2.0);
                 if (HAS(HLX_F_VALIDATION)) sum = nan_guard(sum, 20.0);
                 mvel = v3((float)((double)mvel.x + sum.x * c.dt64), (float)((double)mvel.y + sum.y * c.dt64),
                           (float)((double)mvel.z + sum.z * c.dt64));                // :1116
@@ -216,12 +251,8 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     ti = c.ti_mid * (1.0f - (walt / c.bl_height) * 0.7f);           // :343-346
                 } else { prof = c.bl_prof; ti = c.ti_high; }
                 V3 w = v3(c.base_wind[0] * prof, c.base_wind[1] * prof, c.base_wind[2] * prof);
-                D3 z; double gu;
-                if (noise_buf) { z = d3(SN[3 * N], SN[4 * N], SN[5 * N]); gu = SN[6 * N]; }
-                else {
-                    V3 zf; float w_; rng.normals4(RS_WIND, zf.x, zf.y, zf.z, w_); z = to_d3(zf);
-                    gu = (double)u01(rng.raw(RS_STEP_U).w);
-                }
+                const D3 z = z_wind;
+                const double gu = u_gust;
                 if (ti > 0.f) {                                                     // :370-378
                     double scale = (double)(ti * snorm3(w));
                     w = v3((float)((double)w.x + (scale * z.x) * c.turb_lp), (float)((double)w.y + (scale * z.y) * c.turb_lp),
@@ -237,9 +268,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                 }
                 wind = to_d3(w);
             } else if (simple_wind) {                                               // :1127-1129
-                D3 z;
-                if (noise_buf) z = d3(SN[3 * N], SN[4 * N], SN[5 * N]);
-                else { V3 zf; float w_; rng.normals4(RS_WIND, zf.x, zf.y, zf.z, w_); z = to_d3(zf); }
+                const D3 z = z_wind;
                 auto upd = [&](double w, float base, double zz) {
                     double t1 = w64 ? 0.95 * w : (double)(0.95f * (float)w);
                     return t1 + 0.05 * ((double)base + zz * c.wind_var);
@@ -350,7 +379,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     }
                     // ---------------- spawn (environment.py:375-567): float64 draws cast to float32
                     const KCold& k = *a.cold;
-                    const bool rbuf = a.reset_noise != nullptr;
+                    const bool rbuf = rnoise_buf;
                     double u[10];
                     if (rbuf) {
 #pragma unroll
@@ -430,18 +459,21 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
             }
             if (act) {
                 // ======================================================== core.py:511-691 radar detection
-                float n_on, n_g;
-                double n_dl;
-                D3 n_gp, n_gv;
-                const bool from_buf = (pass == 0) ? noise_buf : (a.reset_noise != nullptr);
-                if (from_buf) {
-                    const double* B = (pass == 0) ? (SN + 11 * N) : (RN + 10 * N);
-                    n_on = (float)B[0]; n_g = (float)B[1 * N]; n_gp = d3(B[2 * N], B[3 * N], B[4 * N]);
-                    n_gv = d3(B[5 * N], B[6 * N], B[7 * N]); n_dl = B[8 * N];
-                } else {
-                    uint4 x = rng.raw(pass == 0 ? RS_STEP_U : RS_RESET_OBS_U);
-                    n_on = u01(x.x); n_g = u01(x.y); n_dl = (double)u01(x.z);
-                    n_gp = n_gv = d3(0., 0., 0.);   // drawn below, only if the ground radar detects
+                float n_on = u_on, n_g = u_g;
+                double n_dl = u_dl;
+                D3 n_gp = z_gp, n_gv = z_gv;
+                if (pass == 1) {   // first observation of a new episode: its own draws
+                    if (rnoise_buf) {
+                        const double* B = RN + 10 * N;
+                        n_on = (float)B[0]; n_g = (float)B[1 * N]; n_gp = d3(B[2 * N], B[3 * N], B[4 * N]);
+                        n_gv = d3(B[5 * N], B[6 * N], B[7 * N]); n_dl = B[8 * N];
+                    } else {
+                        const uint4 x = rng.raw(RS_RESET_OBS_U);
+                        n_on = u01(x.x); n_g = u01(x.y); n_dl = (double)u01(x.z);
+                        V3 f; float w_;
+                        rng.normals4(RS_RESET_GPOS, f.x, f.y, f.z, w_); n_gp = to_d3(f);
+                        rng.normals4(RS_RESET_GVEL, f.x, f.y, f.z, w_); n_gv = to_d3(f);
+                    }
                 }
                 const V3 rel = mpos - ipos;
                 const float range = snorm3(rel);
@@ -486,12 +518,6 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                         float dpq = ((c.g_base_q * (1.0f - (grange / c.g_max_range) * 0.4f)) * c.weather) * a.g_rel;
                         if (n_g > dpq) g_det = false;
                         else {
-                            if (!from_buf) {
-                                V3 p_, v_; float w0_, w1_;
-                                rng.normals4(pass == 0 ? RS_GPOS : RS_RESET_GPOS, p_.x, p_.y, p_.z, w0_);
-                                rng.normals4(pass == 0 ? RS_GVEL : RS_RESET_GVEL, v_.x, v_.y, v_.z, w1_);
-                                n_gp = to_d3(p_); n_gv = to_d3(v_);
-                            }
                             // :422-429 float64 measurement (kept float64 through the delay ring: the Kalman
                             // velocity estimate is tiny while detections are continuous, so outputs such as the
                             // lead-angle cosine are sensitive to 1e-4 m of measurement rounding)
@@ -512,11 +538,9 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     g_sp = g_pos; g_sq = g_q; g_sflag = g_det ? 1.f : 0.f;
                     g_s2 = make_float4(g_vel.x, g_vel.y, g_vel.z, 0.f);
                     d_gp64 = d3(0., 0., 0.); d_gv = v3(0.f, 0.f, 0.f); d_gq = 0.f; d_g_det = false; d_g64 = false;
-                    if (pass == 0 && steps >= c.g_delay) {
-                        int slot = (int)((t + 1ull) % (unsigned long long)g_cap);   // == (t - g_delay) mod g_cap
-                        const float4* R = a.gring + ((size_t)slot * GROUND_RING_WORDS16) * N + i;
-                        double2 s0 = *reinterpret_cast<const double2*>(R);
-                        float4 s1 = R[N], s2 = R[2 * N];
+                    if (pass == 0 && steps >= c.g_delay) {                          // sample pre-loaded at kernel entry
+                        const double2 s0 = gr0;
+                        const float4 s1 = gr1, s2 = gr2;
                         d_gp64 = d3(s0.x, s0.y, __hiloint2double(__float_as_int(s1.y), __float_as_int(s1.x)));
                         d_gq = s1.z; d_g64 = s1.w != 0.f; d_gv = v3(s2.x, s2.y, s2.z);
                         d_g_det = g_det;                                            // :626 CURRENT flag (reference quirk)
