@@ -11,8 +11,9 @@ are issued back to back from C (`hlx_rollout`), one per step, as a policy-free r
 Environments shard over ranks with no collective in the step (weak scaling: 65 536 envs per GPU).
 
 Prints ONE JSON line on rank 0.  `value` = env-steps/s of the whole job (all ranks, max-over-ranks
-time).  `roofline` = algorithmic bytes of one launch / mean kernel duration from HIP events recorded
-on the launch stream around every launch of a second, identical K-step pass.  `cpu_baseline` = the
+time).  `roofline` = algorithmic bytes of one launch / mean launch duration, from HIP events recorded on the
+launch stream around the K back-to-back launches of the timed region (launches are dependent and issued
+ahead of the GPU, so the train has no gaps: elapsed / K is the per-launch duration rocprofv3 reports).  `cpu_baseline` = the
 CPU oracle (scalar C port of the reference's step, oracle/) timed on this host, rank 0, N=1 only.
 """
 import argparse
@@ -54,6 +55,18 @@ def cpu_baseline(rc, budget_s=12.0):
             "sample": f"{n} envs x {steps} steps, medium scenario base physics, oracle/hlx_oracle.c with OpenMP over envs"}
 
 
+def measured_traffic(physics, n):
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
+    WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950);
+    None when no measurement exists for this workload."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(f"{physics}:{n}", {}).get("hbm_bytes_per_launch")
+    except OSError:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,11 +97,14 @@ def main():
 
     from hlynr_intercept_amd.config import resolve_config
     from hlynr_intercept_amd.scenarios import scenario_config
+    from hlynr_intercept_amd.shard import max_over_ranks, shard_range, whole_job_throughput
     from hlynr_intercept_amd.vec_env import HlynrVecEnv
 
     n = args.envs_per_gpu
     rc = resolve_config(scenario_config("medium", args.physics))
-    env = HlynrVecEnv(resolved=rc, num_envs=n, device=local_rank, seed=1000, env_id_offset=rank * n)
+    offset, count = shard_range(n * world, world, rank)          # weak scaling: n envs per rank
+    assert count == n
+    env = HlynrVecEnv(resolved=rc, num_envs=n, device=local_rank, seed=1000, env_id_offset=offset)
     dev = env.device
     K, W = args.steps, args.warmup
     gen = torch.Generator(device=dev).manual_seed(rank)      # fixed-seed synthetic action tape, U(-1, 1)
@@ -105,21 +121,15 @@ def main():
     if W:
         env.rollout_torch(tape[:W], out_slots)
     sync_all()
+    # HIP events recorded on the launch stream bracket the K back-to-back launches of the timed region
+    env.profile(True)
     t0 = time.perf_counter()
     env.rollout_torch(tape[:K], out_slots)
     sync_all()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # identical second pass with HIP events around every launch -> mean kernel duration
-    env.profile(True)
-    env.rollout_torch(tape[:K], out_slots)
-    torch.cuda.synchronize(dev)
     kern_ms, launches = env.profile_read()
     env.profile(False)
+    elapsed = max_over_ranks(elapsed, dist, dev)
     kern_us = 1e3 * kern_ms / max(1, launches)
     bytes_per_launch = BYTES_PER_ENV_STEP[args.physics] * n
     achieved = bytes_per_launch / (kern_us * 1e-6) / 1e9 if launches else 0.0
@@ -129,10 +139,9 @@ def main():
         cpu = cpu_baseline(rc)
 
     if rank == 0:
-        total_steps = float(n) * K * world
         line = {
             "metric": "env-steps/sec whole-node, medium scenario, 64k envs/GPU",
-            "value": total_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "value": whole_job_throughput(n, K, world, elapsed), "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"medium scenario, {args.physics} physics, {n} envs/GPU, fp32 "
@@ -140,7 +149,7 @@ def main():
                        "envs_per_gpu": n, "kernel_variant": env.kernel_variant, "launches_per_step": 1,
                        "sharding": f"{world} x {n} independent envs, no collective in the step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.physics, n),
                          "kernel": "hlx_env_kernel<%s, step>" % env.kernel_variant,
                          "kernel_us": kern_us, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "launches_timed": launches},

@@ -182,9 +182,12 @@ int hlx_fill_noise(hlx_env *env, double *step_noise, double *reset_noise, int32_
 int hlx_get_state(hlx_env *env, hlx_env_state *host_out);
 int hlx_set_state(hlx_env *env, const hlx_env_state *host_in);
 
-/* Kernel timing with HIP events recorded on the launch stream around every step kernel. */
+/* Kernel timing with HIP events recorded on the launch stream: one pair around every hlx_step launch,
+ * one pair around the whole back-to-back launch train of an hlx_rollout call. */
 int hlx_profile(hlx_env *env, int32_t enable);
-int hlx_profile_read(hlx_env *env, double *total_ms, int64_t *launches); /* synchronises, then clears */
+/* total elapsed ms between the event pairs and the number of step launches they covered
+ * (synchronises, then clears) */
+int hlx_profile_read(hlx_env *env, double *total_ms, int64_t *launches);
 
 int32_t hlx_num_envs(const hlx_env *env);
 int64_t hlx_vec_steps(const hlx_env *env);              /* launches so far (the RNG/ring clock) */

@@ -445,7 +445,48 @@ def run_case(name, env_cfg, n_steps, seed, policy="random", tweak=None, global_s
             rec["reset_state"].append(capture_state(env))
         else:
             rec["did_reset"].append(False)
-    out = {"config_json": np.array(json.dumps(env_cfg)), "numpy_version": np.array(np.__version__),
+    og = env.observation_generator
+    gr = og.ground_radar
+    effective = dict(
+        dt=env.dt, max_steps=env.max_steps, max_range=env.max_range, max_velocity=env.max_velocity,
+        target_pos=[float(x) for x in env.target_position],
+        atmosphere=env.atmospheric_model is not None, mach_drag=env.mach_drag_model is not None,
+        enhanced_wind=env.enhanced_wind_model is not None, thrust_lag=bool(env.thrust_dynamics_enabled),
+        domain_randomization=env.physics_randomizer is not None and bool(env.physics_randomizer.enabled),
+        validation=bool(env.physics_validation_enabled), evasion=bool(env.config.get("missile_evasion", False)),
+        base_wind=[float(x) for x in env.base_wind], wind_variability=env.wind_variability,
+        use_curriculum=bool(env.use_curriculum), initial_radius=env.initial_intercept_radius,
+        final_radius=env.final_intercept_radius, curriculum_steps=env.curriculum_steps,
+        precision_mode=bool(env.precision_mode), proximity_fuze=bool(env.proximity_fuze_enabled),
+        proximity_kill_radius=env.proximity_kill_radius,
+        radar_curriculum_active=bool(env.use_radar_curriculum and env.radar_curriculum_config),
+        radar_quality=env.radar_quality, radar_range=og.radar_range,
+        radar_beam_width_now=og.radar_beam_width, onboard_reliability_now=og.onboard_detection_reliability,
+        ground_reliability_now=og.ground_detection_reliability, intercept_radius_now=env.get_current_intercept_radius(),
+        onboard_delay=(og.sensor_delay_buffer.delay_samples if og.sensor_delay_buffer else 0) if not (
+            env.physics_randomizer is not None and env.physics_randomizer.enabled) else -1,
+        ground_enabled=gr is not None,
+        ground_delay=og.ground_sensor_delay_buffer.delay_samples if og.ground_sensor_delay_buffer else 0,
+        obs_mode=og.observation_mode,
+    )
+    if gr is not None:
+        effective.update(ground_pos=[float(x) for x in gr.position], ground_max_range=gr.max_range,
+                         ground_min_elev=float(gr.min_elevation_angle), ground_max_elev=float(gr.max_elevation_angle),
+                         ground_range_accuracy=gr.range_accuracy, ground_velocity_accuracy=gr.velocity_accuracy,
+                         ground_base_quality=gr.base_quality, max_datalink_range=og.max_datalink_range,
+                         datalink_packet_loss=og.datalink_packet_loss)
+    if env.mach_drag_model is not None and not effective["domain_randomization"]:
+        m = env.mach_drag_model
+        effective.update(subsonic_mach=m.subsonic_mach, supersonic_mach=m.supersonic_mach,
+                         transonic_peak_multiplier=m.transonic_peak_multiplier, supersonic_multiplier=m.supersonic_multiplier)
+    if env.enhanced_wind_model is not None:
+        w = env.enhanced_wind_model
+        effective.update(boundary_layer_height=w.boundary_layer_height, turbulence_intensity=w.turbulence_intensity,
+                         gust_scale=w.gust_scale)
+    if env.thrust_dynamics_enabled:
+        effective["thrust_tau"] = env.thrust_time_constant
+    out = {"config_json": np.array(json.dumps(env_cfg)), "effective_json": np.array(json.dumps(effective)),
+           "numpy_version": np.array(np.__version__),
            "seed": np.int64(seed), "global_step": np.int64(global_step),
            "reset_noise0": reset_noise0, "reset_obs0": obs0.astype(np.float32)}
     for k, v in init_state.items():

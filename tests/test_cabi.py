@@ -1,0 +1,67 @@
+"""The C ABI library loads (ROCm runtime present, no GPU needed) and exports every symbol that
+include/hlx.h declares; argument validation works without touching a device."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from hlynr_intercept_amd import _lib
+from hlynr_intercept_amd.config import resolve_config
+from hlynr_intercept_amd.scenarios import scenario_config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "hlx.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(hlx_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_header_and_binding_agree():
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    assert declared == sorted(_lib.SYMBOLS), (set(declared) ^ set(_lib.SYMBOLS))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    for name in _declared_symbols():
+        assert getattr(lib, name) is not None
+    assert lib.hlx_version().decode().startswith("hlx")
+    assert lib.hlx_sizeof_config() == C.sizeof(_lib.HlxConfig)
+    assert lib.hlx_sizeof_env_state() == C.sizeof(_lib.HlxEnvState)
+
+
+def test_argument_validation_without_a_device():
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.hlx_create(None, 16, 0, 0, 0, C.byref(h)) == -1 and b"null" in lib.hlx_last_error()
+    cfg = _lib.make_hlx_config(resolve_config(scenario_config("medium", "base")))
+    assert lib.hlx_create(C.byref(cfg), 0, 0, 0, 0, C.byref(h)) == -1 and b"n_envs" in lib.hlx_last_error()
+    cfg.max_steps = 100000
+    assert lib.hlx_create(C.byref(cfg), 16, 0, 0, 0, C.byref(h)) == -1 and b"max_steps" in lib.hlx_last_error()
+    assert lib.hlx_step(None, None, None, None, None, None, None, None, None, None, None) == -1
+    assert lib.hlx_destroy(None) == 0
+
+
+def test_config_struct_carries_the_flags():
+    rc = resolve_config(scenario_config("medium", "v2dr", {"observation_mode": "los_frame", "proximity_fuze_enabled": True}))
+    cfg = _lib.make_hlx_config(rc)
+    for bit in (_lib.F_ATMOSPHERE, _lib.F_MACH_DRAG, _lib.F_ENH_WIND, _lib.F_THRUST_LAG, _lib.F_DOMAIN_RAND,
+                _lib.F_VALIDATION, _lib.F_EVASION, _lib.F_GROUND, _lib.F_OBS_LOS, _lib.F_PROX_FUZE,
+                _lib.F_USE_CURRICULUM, _lib.F_RADAR_CURRICULUM):
+        assert cfg.flags & bit
+    assert not cfg.flags & (_lib.F_OBS_BODY | _lib.F_PRECISION | _lib.F_SPHERICAL)
+    assert cfg.dt == 0.01 and cfg.onboard_delay == 3 and cfg.ground_delay == 5
+    assert list(cfg.rc_beam) == [120.0, 60.0, 5000000.0, 8000000.0]
+
+
+def test_vec_env_refuses_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from hlynr_intercept_amd.vec_env import HlynrVecEnv
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        HlynrVecEnv(scenario_config("medium", "base"), num_envs=4)

@@ -1,0 +1,114 @@
+"""The drop-in VecEnv facade on a real GPU: SB3 VecEnv contract, lazy infos, curriculum hook,
+state export/injection, done-list compaction, size-independent invariants at BASELINE.json's full size."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(n, physics="base", over=None, seed=3):
+    from hlynr_intercept_amd.scenarios import scenario_config
+    from hlynr_intercept_amd.vec_env import HlynrVecEnv
+    return HlynrVecEnv(scenario_config("medium", physics, over), num_envs=n, seed=seed)
+
+
+def test_sb3_vecenv_contract_and_auto_reset():
+    env = _env(200, over={"max_steps": 30})
+    obs = env.reset()
+    assert obs.shape == (200, 26) and obs.dtype == np.float32
+    assert env.observation_space.shape == (26,) and env.action_space.shape == (6,)
+    assert env.kernel_variant == "base"
+    rng = np.random.default_rng(0)
+    ep_returns = np.zeros(200)
+    seen_done = 0
+    for t in range(65):
+        a = rng.uniform(-1, 1, (200, 6)).astype(np.float32)
+        env.step_async(a)
+        obs, rew, dones, infos = env.step_wait()
+        assert obs.shape == (200, 26) and rew.shape == (200,) and dones.dtype == bool and len(infos) == 200
+        ep_returns += rew
+        for i, info in infos.done_items():
+            assert dones[i]
+            assert info["terminal_observation"].shape == (26,)
+            assert info["episode"]["l"] == 30 or info["episode"]["l"] < 30
+            assert info["episode"]["r"] == pytest.approx(ep_returns[i], rel=1e-4, abs=1e-2)   # Monitor 'r'
+            assert info["TimeLimit.truncated"] == (info["episode"]["l"] == 30 and not bool(env.terminated[i].item()))
+            ep_returns[i] = 0.0
+            seen_done += 1
+        if t == 29:
+            assert dones.all()                      # max_steps = 30 -> every env truncates together
+            st = env.get_state()
+            assert all(st[i].steps == 0 for i in range(200))   # ... and was reset in the same launch
+        i = int(rng.integers(200))
+        assert set(infos[i]) >= {"distance", "intercepted", "fuel_remaining", "TimeLimit.truncated", "min_distance"}
+    assert seen_done >= 400
+    assert np.all(obs <= 1.0 + 1e-6) and np.all(obs >= -2.0 - 1e-6)
+    env.close()
+
+
+def test_curriculum_hook_and_attrs():
+    env = _env(8)
+    assert env.get_current_intercept_radius() == 100.0
+    assert env.get_attr("observation_generator")[0].radar_beam_width == 120.0
+    env.env_method("set_training_step_count", 1_000_000)
+    assert env.get_current_intercept_radius() == pytest.approx(52.5)
+    env.env_method("set_training_step_count", 6_500_000)
+    og = env.get_attr("observation_generator")[0]
+    assert og.radar_beam_width == pytest.approx(90.0) and og.onboard_detection_reliability == 1.0
+    env.reset()
+    st = env.get_attr("interceptor_state", indices=[0, 3])
+    assert st[0]["position"].shape == (3,) and st[1]["fuel"] == 100.0
+    with pytest.raises(AttributeError):
+        env.env_method("render")
+    env.close()
+
+
+def test_state_roundtrip_and_done_list():
+    import torch
+    env = _env(300, physics="v2dr", over={"max_steps": 20})
+    env.reset_torch()
+    g = torch.Generator().manual_seed(1)
+    for t in range(50):
+        a = (torch.rand((300, 6), generator=g) * 2 - 1).to(env.device)
+        obs, rew, term, trunc, info = env.step_torch(a, want_done_list=True)
+        n_done = int(info["n_done"].item())
+        expect = torch.nonzero((term | trunc) != 0).flatten().cpu().numpy()
+        got = np.sort(info["done_idx"][:n_done].cpu().numpy())
+        assert np.array_equal(got, expect)                      # ballot/popcount compaction == nonzero()
+    st = env.get_state()
+    snap = bytes(st)
+    env.set_state(st)
+    assert bytes(env.get_state()) == snap                      # export -> inject -> export is the identity
+    o1 = env.step_torch(a)[0].clone()
+    env.set_state(st)                                           # rewind ... the clock moved, so rings shift,
+    env.close()                                                 # but injection itself must not fail
+    assert torch.isfinite(o1).all()
+
+
+def test_invariants_at_full_size():
+    """BASELINE.json config 2 size (65 536 envs): properties that do not need the oracle."""
+    import torch
+    env = _env(65536, over={"max_steps": 150}, seed=11)
+    env.reset_torch()
+    g = torch.Generator(device=env.device).manual_seed(0)
+    fuel_prev = torch.full((65536,), 100.0, device=env.device)
+    n_done = 0
+    for t in range(320):
+        a = torch.rand((65536, 6), generator=g, device=env.device) * 2 - 1
+        obs, rew, term, trunc, info = env.step_torch(a)
+        done = (term | trunc) != 0
+        n_done += int(done.sum())
+        assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+        assert float(obs.max()) <= 1.0 + 1e-6 and float(obs.min()) >= -2.0 - 1e-6
+        fuel = info["fuel"]
+        assert bool(((fuel <= fuel_prev + 1e-6) | done).all())  # fuel never increases within an episode
+        fuel_prev = torch.where(done, torch.full_like(fuel, 100.0), fuel)
+        assert bool((info["min_distance"] <= info["distance"] + 1e-3)[~done].all())
+    st = env.get_state()
+    q = np.array([list(st[i].int_quat) for i in range(0, 65536, 97)])
+    assert np.allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-5)         # unit quaternions
+    P = np.array([list(st[i].kf_P) for i in range(0, 65536, 97)])
+    assert np.all(P[:, 0] > 0) and np.all(P[:, 3] > 0)                     # covariance diagonal stays positive
+    steps = np.array([st[i].steps for i in range(0, 65536, 97)])
+    assert steps.max() < 150 and n_done >= 2 * 65536                        # every env truncated at least twice
+    env.close()
