@@ -7,7 +7,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB = os.path.join(_HERE, "libhlx.so")
+LIB = os.environ.get("HLX_LIBRARY") or os.path.join(_HERE, "libhlx.so")   # HLX_LIBRARY: diagnostic builds
 SOURCES = ["hlx_kernels.hip"]
 DEPS = ["hlx_kernels.hip", "hlx_host.inc", "hlx_device.h", "hlx_kargs.h", os.path.join("..", "..", "include", "hlx.h")]
 
@@ -20,6 +20,8 @@ def _hipcc() -> str:
 
 
 def needs_build() -> bool:
+    if os.environ.get("HLX_LIBRARY"):
+        return False
     if not os.path.exists(LIB):
         return True
     mt = os.path.getmtime(LIB)
@@ -29,12 +31,21 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unused-value",
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-Wno-unused-value",
            "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
     return LIB
+
+
+def build_stamps(level: int = 1) -> str:
+    """Diagnostic build with s_memtime stamps (tools/diag_stamps.py); never used by the product path."""
+    out = os.path.join(_HERE, "libhlx_stamps.so")
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                           "-mllvm", "-amdgpu-kernarg-preload-count=16", "-Wno-unused-value", f"-DHLX_STAMPS={level}", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES],
+                          cwd=CSRC)
+    return out
 
 
 if __name__ == "__main__":

@@ -66,31 +66,41 @@ struct KCold {
     double dr_var[5];
 };
 
-struct KArgs {
-    KCfg c;
-    const KCold* cold;
-    float radius, on_rel, g_rel;  // curriculum scalars in force for this launch
-    double half_beam;
-    float4* arena;
-    float4* gring;  // [g_delay+1][GROUND_RING_WORDS16][N]
-    float4* oring;  // [o_cap][N]
-    int32_t n;
-    const float* actions;
-    float* obs;
-    float* reward;
-    uint8_t* term;
-    uint8_t* trunc;
+// ---------------------------------------------------------------------------------------------------
+// Kernel arguments.  The kernarg segment of a launch is freshly written memory: a scalar load from it misses
+// every cache (~2-3k cycles), and a wave that is alone on its SIMD eats all of it (round-1 stamps: 12-20 % of
+// the wave lifetime went before the first load was issued).  So:
+//   * the kernel's first 14 parameter dwords -- arena, P, actions, clock, seed, env offset, n, ring slots -- are
+//     PRELOADED into SGPRs by the dispatcher (-amdgpu-kernarg-preload-count=16): no scalar load stands between
+//     wave start and the state/action/ring loads or the Philox block; the output pointers follow in an ordinary
+//     kernarg tail whose load is issued at entry and first needed when results are stored;
+//   * everything that is fixed for the handle, or changes rarely (optional output buffers, curriculum scalars),
+//     lives in ONE device-resident block *P that stays hot in L2 and is re-uploaded only when it changes.
+// ---------------------------------------------------------------------------------------------------
+struct KOpt {              // optional caller buffers (re-uploaded only when the pointers change)
     float* terminal_obs;
     int32_t* done_idx;
-    int32_t* done_cnt;  // [2], double-buffered by vec-step parity
     hlx_info_soa info;
-    const double* step_noise;   // parity mode: slot-major [HLX_STEP_SLOTS][N] float64 unit draws (NULL = Philox)
-    const double* reset_noise;  // [HLX_RESET_SLOTS][N]
-    const unsigned long long* t_dev;  // optional device-resident clock base (hipGraph replay)
-    unsigned long long t_add;
-    uint32_t seed_lo, seed_hi;
-    long long env_offset;
+    const double* step_noise;    // parity mode: slot-major [HLX_STEP_SLOTS][N] float64 unit draws (NULL = Philox)
+    const double* reset_noise;   // [HLX_RESET_SLOTS][N]
     const uint8_t* reset_mask;
+};
+struct KCur {              // curriculum scalars in force (re-uploaded when hlx_set_global_step changes them)
+    double half_beam;
+    float radius, on_rel, g_rel, pad;
+};
+struct KParams {           // device-resident
+    KCfg c;
+    KCur cur;
+    KOpt opt;
+    KCold cold;
+    float4* gring;         // [g_delay+1][GROUND_RING_WORDS16][N]
+    float4* oring;         // [o_cap][N]
+    int32_t* done_cnt;     // [2], double-buffered by vec-step parity
+    unsigned long long* stamps;   // diagnostic builds only (-DHLX_STAMPS): [blocks][16] s_memtime samples
+    long long env_offset;
+    uint32_t seed_lo, seed_hi;
+    int32_t n;
 };
 
 }  // namespace hlx

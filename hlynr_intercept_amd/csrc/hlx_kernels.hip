@@ -32,51 +32,155 @@ namespace {
 
 #define HAS(f) ((FL & (uint32_t)(f)) != 0u)
 
+// Diagnostic build only (-DHLX_STAMPS): lane 0 of every wave records s_memtime at a few program points into
+// a.stamps[block][16].  No stamp executes in the product build, and no output is ever computed from one.
+#ifdef HLX_STAMPS
+#define STAMP_RAW(k)                                                                                       \
+    do {                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        unsigned long long t_;                                                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                      \
+        if (lane == 0 && P->stamps) P->stamps[(size_t)blockIdx.x * 16 + (k)] = t_;                       \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    } while (0)
+// HLX_STAMPS=1: coarse map of the whole wave; HLX_STAMPS=2: slots 1..6 re-used for a close-up of one segment
+#define STAMP(k) do { if (HLX_STAMPS == 1 || (k) == 0 || (k) >= 7) STAMP_RAW(k); } while (0)
+#define STAMP2(k) do { if (HLX_STAMPS == 2) STAMP_RAW(k); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#define STAMP2(k) do { } while (0)
+#endif
+
 DEV double rr(double x, bool is64) { return is64 ? x : (double)(float)x; }
 
 // NOISE = parity-mode instantiation that can take its random draws from caller-supplied float64 buffers;
 // the production instantiation (NOISE = false) contains no trace of that path.
 template <uint32_t SPEC, int MODE /*0 = step, 1 = reset-only*/, bool NOISE>
-__global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
+__global__ __launch_bounds__(64) void hlx_env_kernel(
+    // ---- 14 dwords preloaded into SGPRs by the dispatcher: everything needed to issue the state, action and
+    //      ring loads and to run the Philox block without waiting for memory
+    float4* __restrict__ arena, const KParams* __restrict__ P, const float* __restrict__ actions,
+    const unsigned long long t, const unsigned long long seed, const long long env_offset, const int n,
+    const uint32_t slots,   // bits 0-3 ground-ring read slot, 4-7 ground-ring write slot, 8-11 onboard-ring write slot,
+                            // 12-15 ground-ring planes (delay+1, 0 = no ring), 16-19 onboard-ring planes (0 = no ring)
+    // ---- ordinary kernarg tail (one scalar load, issued at entry, first needed when results are stored)
+    float* __restrict__ obs_out, float* __restrict__ reward_out, uint8_t* __restrict__ term_out,
+    uint8_t* __restrict__ trunc_out) {
     __shared__ __attribute__((aligned(16))) float tile[64 * HLX_OBS_DIM];
-    const uint32_t FL = (SPEC & KF_DYNAMIC) ? a.c.flags : SPEC;
+    const uint32_t FL = (SPEC & KF_DYNAMIC) ? P->c.flags : SPEC;
     const int lane = threadIdx.x;
     const int i = blockIdx.x * 64 + lane;
-    const int n = a.n;
     const bool live = i < n;
-    const unsigned long long t = a.t_add + (a.t_dev ? *a.t_dev : 0ull);
-    const KCfg& c = a.c;
+    const int g_rslot = (int)(slots & 15u), g_wslot = (int)((slots >> 4) & 15u), o_wslot = (int)((slots >> 8) & 15u);
+    const int g_planes = (int)((slots >> 12) & 15u), o_planes = (int)((slots >> 16) & 15u);   // preloaded: no *P needed
+    const KOpt* O = &P->opt;
+    const KCfg& c = P->c;
     float* row = tile + lane * HLX_OBS_DIM;
     bool done = false;
 
+    STAMP(0);
+    // The scalar data cache is invalidated at every dispatch, and the compiler loads config fields lazily, one
+    // line at a time, right where they are first used: each first touch of a 64-byte line of *P would stall the
+    // lone wave of this SIMD for an L2 round trip.  Touch every line of the hot block now (the loads fly together
+    // with the state loads below); `cfg_touch` is consumed after the Philox block, by when they have landed.
+    constexpr int kTouch = (int)((offsetof(KParams, cold) + 63) / 64);
+    static_assert(kTouch <= 8, "hot part of KParams grew: extend the touch list");
+    uint32_t cfg_touch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    {
+        const uint32_t* pw = reinterpret_cast<const uint32_t*>(P);
+#pragma unroll
+        for (int k = 0; k < kTouch; ++k) cfg_touch[k] = pw[k * 16];   // no arithmetic on them: that would wait here
+    }
+    // State loads are issued before anything else, for every lane: the arena is padded to whole 64-env blocks,
+    // its pointer arrives preloaded in SGPRs, and nothing here depends on the rest of the kernel arguments.
+    // arena layout: [workgroup][group][64 lanes] of 16-byte words -> one contiguous ~11 KiB chunk per wave,
+    // group offsets are compile-time constants (no per-group 64-bit address arithmetic in SGPRs)
+    float4* A = arena + (size_t)blockIdx.x * (N_GROUPS * 64) + lane;
+    double2* AD = reinterpret_cast<double2*>(A);
+    // ------------------------------------------------------------------ issue every load up front
+    // (state groups, action row, the delayed ground-ring sample whose slot depends only on the global
+    // clock); the Philox draws below do not depend on them and run while the loads are in flight.
+    float4 g_ipos = A[G_IPOS * 64], g_ivel = A[G_IVEL * 64], g_quat = A[G_QUAT * 64], g_mpos = A[G_MPOS * 64];
+    float4 g_mvel = A[G_MVEL * 64], g_w1 = A[G_W1 * 64], g_kfp = A[G_KFP * 64];
+    double2 g_w0 = AD[G_W0 * 64], g_kf0 = AD[G_KF0 * 64], g_kf1 = AD[G_KF1 * 64], g_kf2 = AD[G_KF2 * 64];
+    float4 g_thr = make_float4(0.f, 0.f, 0.f, 0.f), g_misc = make_float4(288.15f, 0.3f, P->c.peak, 0.f);
+    if (HAS(HLX_F_THRUST_LAG)) g_thr = A[G_THRUST * 64];
+    if (HAS(HLX_F_DOMAIN_RAND)) g_misc = A[G_MISC * 64];
     if (live) {
         const size_t N = (size_t)n;
-        // arena layout: [workgroup][group][64 lanes] of 16-byte words -> one contiguous ~11 KiB chunk per wave,
-        // group offsets are compile-time constants (no per-group 64-bit address arithmetic in SGPRs)
-        float4* A = a.arena + (size_t)blockIdx.x * (N_GROUPS * 64) + lane;
-        double2* AD = reinterpret_cast<double2*>(A);
-        // ------------------------------------------------------------------ issue every load up front
-        // (state groups, action row, the delayed ground-ring sample whose slot depends only on the global
-        // clock); the Philox draws below do not depend on them and run while the loads are in flight.
-        float4 g_ipos = A[G_IPOS * 64], g_ivel = A[G_IVEL * 64], g_quat = A[G_QUAT * 64], g_mpos = A[G_MPOS * 64];
-        float4 g_mvel = A[G_MVEL * 64], g_w1 = A[G_W1 * 64], g_kfp = A[G_KFP * 64];
-        double2 g_w0 = AD[G_W0 * 64], g_kf0 = AD[G_KF0 * 64], g_kf1 = AD[G_KF1 * 64], g_kf2 = AD[G_KF2 * 64];
-        float4 g_thr = make_float4(0.f, 0.f, 0.f, 0.f), g_misc = make_float4(288.15f, 0.3f, c.peak, 0.f);
-        if (HAS(HLX_F_THRUST_LAG)) g_thr = A[G_THRUST * 64];
-        if (HAS(HLX_F_DOMAIN_RAND)) g_misc = A[G_MISC * 64];
+        // rings live right behind the (64-padded) arena in the same allocation: addresses need only preloaded values
+        float4* const gring = arena + (size_t)((n + 63) >> 6) * (N_GROUPS * 64);     // [g_delay+1][3][N]
+        float4* const oring = gring + (size_t)(g_planes * GROUND_RING_WORDS16) * N;   // [o_cap][N]
         float2 a01 = make_float2(0.f, 0.f), a23 = a01, a45 = a01;
         double2 gr0 = make_double2(0., 0.);
         float4 gr1 = make_float4(0.f, 0.f, 0.f, 0.f), gr2 = gr1;
         if (MODE == 0) {
-            const float2* ap = reinterpret_cast<const float2*>(a.actions + (size_t)i * HLX_ACT_DIM);
+            const float2* ap = reinterpret_cast<const float2*>(actions + (size_t)i * HLX_ACT_DIM);
             a01 = ap[0]; a23 = ap[1]; a45 = ap[2];
-            if (HAS(HLX_F_GROUND) && c.g_delay > 0) {
-                const int slot = (int)((t + 1ull) % (unsigned long long)(c.g_delay + 1));   // == (t - g_delay) mod cap
-                const float4* R = a.gring + ((size_t)slot * GROUND_RING_WORDS16) * N + i;
+            if (HAS(HLX_F_GROUND)) {   // unconditional when the station exists (the host always allocates >= 1 slot):
+                                       // a runtime guard here would put a register merge, i.e. a wait, in front of Philox
+                const float4* R = gring + ((size_t)g_rslot * GROUND_RING_WORDS16) * N + i;   // slot (t - g_delay) mod cap
                 gr0 = *reinterpret_cast<const double2*>(R); gr1 = R[N]; gr2 = R[2 * N];
             }
         }
 
+        STAMP(1);   // all loads issued
+        const bool noise_buf = NOISE && O->step_noise != nullptr;
+        const bool rnoise_buf = NOISE && O->reset_noise != nullptr;
+        const unsigned long long gid = (unsigned long long)(env_offset + i);
+        Rng rng{uint2{(uint32_t)seed, (uint32_t)(seed >> 32)}, (uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)t, (uint32_t)(t >> 32)};
+        const double* SN = NOISE ? O->step_noise + i : nullptr;   // slot-major [slot][N] (float64: parity mode replays the reference's draws)
+        const double* RN = NOISE ? O->reset_noise + i : nullptr;
+
+        // ------------------------------------------------------------------ this step's random draws
+        // (five independent Philox chains in one straight-line block: instruction-level parallelism for
+        // the lone wave of this SIMD, and it overlaps the state loads issued above)
+        D3 z_ev = d3(0., 0., 0.), z_wind = z_ev, z_gp = z_ev, z_gv = z_ev;
+        float u_on = 0.f, u_g = 0.f;
+        double u_dl = 0., u_gust = 1.;
+        if (MODE == 0) {
+            if (noise_buf) {
+                z_ev = d3(SN[0 * N], SN[1 * N], SN[2 * N]); z_wind = d3(SN[3 * N], SN[4 * N], SN[5 * N]); u_gust = SN[6 * N];
+                u_on = (float)SN[11 * N]; u_g = (float)SN[12 * N];
+                z_gp = d3(SN[13 * N], SN[14 * N], SN[15 * N]); z_gv = d3(SN[16 * N], SN[17 * N], SN[18 * N]); u_dl = SN[19 * N];
+            } else {
+                // 4 uniforms + 12 normals = four Philox calls (all of them, whatever the feature flags: the block
+                // runs in the shadow of the cold-start memory latency, and the slot -> stream map stays fixed)
+                const uint4 x = rng.raw(RS_STEP_U);
+                float n0, n1, n2, n3, n4, n5, n6, n7, n8, n9, n10, n11;
+                rng.normals4(RS_STEP_N0, n0, n1, n2, n3);
+                rng.normals4(RS_STEP_N1, n4, n5, n6, n7);
+                rng.normals4(RS_STEP_N2, n8, n9, n10, n11);
+                float ua = u01(x.x), ub = u01(x.y), uc = u01(x.z), ud = u01(x.w);
+                // keep the block here (the optimiser would otherwise sink each chain to its first use, behind
+                // the loads it is meant to overlap)
+                asm volatile("" : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "+v"(n4), "+v"(n5), "+v"(n6), "+v"(n7));
+                asm volatile("" : "+v"(n8), "+v"(n9), "+v"(n10), "+v"(n11), "+v"(ua), "+v"(ub), "+v"(uc), "+v"(ud));
+                z_ev = d3((double)n0, (double)n1, (double)n2);
+                z_wind = d3((double)n3, (double)n4, (double)n5);
+                z_gp = d3((double)n6, (double)n7, (double)n8);
+                z_gv = d3((double)n9, (double)n10, (double)n11);
+                u_on = ua; u_g = ub; u_dl = (double)uc; u_gust = (double)ud;
+            }
+        }
+
+        // Loaded registers become visible to the optimiser only here: without these fake defs it hoists the first
+        // cheap use of a loaded value (a flag compare) above the Philox block, and the wave would sit out the
+        // cold-start latency BEFORE doing the one piece of work that needs no memory.
+#define PIN4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
+#define PIN2(v) asm volatile("" : "+v"((v).x), "+v"((v).y))
+        PIN4(g_ipos); PIN4(g_ivel); PIN4(g_quat); PIN4(g_mpos); PIN4(g_mvel); PIN4(g_w1); PIN4(g_kfp);
+        PIN2(g_w0); PIN2(g_kf0); PIN2(g_kf1); PIN2(g_kf2);
+        if (HAS(HLX_F_THRUST_LAG)) PIN4(g_thr);
+        if (HAS(HLX_F_DOMAIN_RAND)) PIN4(g_misc);
+        PIN2(a01); PIN2(a23); PIN2(a45); PIN2(gr0); PIN4(gr1); PIN4(gr2);
+#undef PIN4
+#undef PIN2
+        // config lines are resident in the scalar cache, and the output pointers of the kernarg tail have landed
+        asm volatile("" ::"s"(cfg_touch[0]), "s"(cfg_touch[1]), "s"(cfg_touch[2]), "s"(cfg_touch[3]), "s"(cfg_touch[4]),
+                     "s"(cfg_touch[5]), "s"(cfg_touch[6]), "s"(cfg_touch[7]), "s"(obs_out), "s"(reward_out), "s"(term_out),
+                     "s"(trunc_out));
+        STAMP(2);   // Philox block done (loads still in flight)
         V3 ipos = v3(g_ipos.x, g_ipos.y, g_ipos.z), ivel = v3(g_ivel.x, g_ivel.y, g_ivel.z);
         Quat q = Quat{g_quat.x, g_quat.y, g_quat.z, g_quat.w};
         V3 mpos = v3(g_mpos.x, g_mpos.y, g_mpos.z), mvel = v3(g_mvel.x, g_mvel.y, g_mvel.z);
@@ -93,37 +197,6 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
         float T0 = g_misc.x;
         DragParams dp{c.subsonic, c.supersonic, c.mach_span, g_misc.z, g_misc.y, c.cd_super};
         if (HAS(HLX_F_DOMAIN_RAND)) dp.cd_super = (float)((double)dp.base_cd * c.super_mult);
-
-        const bool noise_buf = NOISE && a.step_noise != nullptr;
-        const bool rnoise_buf = NOISE && a.reset_noise != nullptr;
-        const unsigned long long gid = (unsigned long long)(a.env_offset + i);
-        Rng rng{uint2{a.seed_lo, a.seed_hi}, (uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)t, (uint32_t)(t >> 32)};
-        const double* SN = a.step_noise + i;   // slot-major [slot][N] (float64: parity mode replays the reference's draws)
-        const double* RN = a.reset_noise + i;
-
-        // ------------------------------------------------------------------ this step's random draws
-        // (five independent Philox chains in one straight-line block: instruction-level parallelism for
-        // the lone wave of this SIMD, and it overlaps the state loads issued above)
-        D3 z_ev = d3(0., 0., 0.), z_wind = z_ev, z_gp = z_ev, z_gv = z_ev;
-        float u_on = 0.f, u_g = 0.f;
-        double u_dl = 0., u_gust = 1.;
-        if (MODE == 0) {
-            if (noise_buf) {
-                z_ev = d3(SN[0 * N], SN[1 * N], SN[2 * N]); z_wind = d3(SN[3 * N], SN[4 * N], SN[5 * N]); u_gust = SN[6 * N];
-                u_on = (float)SN[11 * N]; u_g = (float)SN[12 * N];
-                z_gp = d3(SN[13 * N], SN[14 * N], SN[15 * N]); z_gv = d3(SN[16 * N], SN[17 * N], SN[18 * N]); u_dl = SN[19 * N];
-            } else {
-                V3 f; float w_;
-                if (HAS(HLX_F_EVASION)) { rng.normals4(RS_EVASION, f.x, f.y, f.z, w_); z_ev = to_d3(f); }
-                if (HAS(HLX_F_ENH_WIND) || c.wind_var > 0.0) { rng.normals4(RS_WIND, f.x, f.y, f.z, w_); z_wind = to_d3(f); }
-                const uint4 x = rng.raw(RS_STEP_U);
-                u_on = u01(x.x); u_g = u01(x.y); u_dl = (double)u01(x.z); u_gust = (double)u01(x.w);
-                if (HAS(HLX_F_GROUND)) {
-                    rng.normals4(RS_GPOS, f.x, f.y, f.z, w_); z_gp = to_d3(f);
-                    rng.normals4(RS_GVEL, f.x, f.y, f.z, w_); z_gv = to_d3(f);
-                }
-            }
-        }
 
         float reward = 0.f, distance = 0.f;
         bool terminated = false, truncated = false, intercepted = false, hit_target = false, fuze = false,
@@ -153,6 +226,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
             const bool simple_wind = !HAS(HLX_F_ENH_WIND) && c.wind_var > 0.0;
             const bool w64 = simple_wind && steps > 1;
 
+            STAMP(3);   // first use of loaded state + clamp done
             // -------------------------------------------------------------- interceptor (environment.py:861-956)
             V3 thr = at * 10000.f, ang = aw * 20.f;                                 // :870-871
             if (HAS(HLX_F_THRUST_LAG)) {                                            // :874-878
@@ -207,6 +281,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     q = Quat{r.w / nq, r.x / nq, r.y / nq, r.z / nq};
                 }
             }
+            STAMP(4);   // interceptor integrated
             // -------------------------------------------------------------- missile (environment.py:1069-1117)
             {
                 float mrho = 1.225f, msos = 343.f;
@@ -241,6 +316,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                           (float)((double)mvel.z + sum.z * c.dt64));                // :1116
                 mpos = mpos + mvel * c.dt;                                          // :1117
             }
+            STAMP(5);   // missile integrated
             // -------------------------------------------------------------- wind (environment.py:1119-1129)
             if (HAS(HLX_F_ENH_WIND)) {                                              // physics_models.py:351-387
                 float walt = fmaxf(ipos.z, 0.f);
@@ -279,7 +355,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
             V3 rel = mpos - ipos;
             distance = snorm3(rel);
             if (HAS(HLX_F_PROX_FUZE)) intercepted = distance < c.kill_radius;       // :700-703
-            else intercepted = distance < a.radius;
+            else intercepted = distance < P->cur.radius;
             min_distance = (distance < min_distance) ? distance : min_distance;     // :706
             if (intercepted) crossed = true;                                        // :709-710
             if (HAS(HLX_F_PROX_FUZE) && min_distance < c.kill_radius) { fuze = true; intercepted = true; } // :715-717
@@ -301,13 +377,14 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                 if (worsening > 500 && distance > 2500.f) terminated = true;
             }
             truncated = steps >= c.max_steps;                                       // :813-814
+            STAMP(6);   // wind + termination
             // -------------------------------------------------------------- reward (:1131-1320)
             if (HAS(HLX_F_PRECISION)) {
                 if (terminated) {                                                   // :1155-1201
                     float md = min_distance;
                     if (crossed) {
                         reward = 3000.f;
-                        if (md < a.radius) reward = reward + ((a.radius - md) / a.radius) * 1000.f;
+                        if (md < P->cur.radius) reward = reward + ((P->cur.radius - md) / P->cur.radius) * 1000.f;
                         reward = reward + expf(divc(-md, 1.0 / 25.0)) * 500.f;
                         reward = reward + expf(divc(-md, 1.0 / 10.0)) * 1000.f;
                         reward = reward + expf(divc(-md, 1.0 / 3.0)) * 500.f;
@@ -351,34 +428,36 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
             ep_return += reward;
         } else {
             // reset-only launch: `done` marks the envs to reset
-            done = a.reset_mask ? (a.reset_mask[i] != 0) : true;
+            done = O->reset_mask ? (O->reset_mask[i] != 0) : true;
         }
 
+        STAMP(7);   // reward
         // ---------------------------------------------------------------------- observation (+ auto-reset)
         // pass 0: observation of the stepped state.  pass 1 (only if some lane of the wave finished):
         // finished lanes respawn (environment.py:353-603) and build their first observation.
-        const int g_cap = c.g_delay + 1, o_cap = c.o_cap;
+        const int o_cap = c.o_cap;
         float4 on_sample = make_float4(0.f, 0.f, 0.f, 0.f), g_s2 = on_sample;
         D3 g_sp = d3(0., 0., 0.);          // ground ring sample: float64 measured rel_pos, float32 quality/flag, rel_vel
         float g_sq = 0.f, g_sflag = 0.f;
         uint32_t det_bits = 0;
 #pragma unroll 1
         for (int pass = (MODE == 0 ? 0 : 1); pass < 2; ++pass) {
+            STAMP2(1);  // close-up: loop top
             const bool act = (pass == 0) || done;
             if (pass == 1) {
                 if (__ballot(done) == 0ull) break;
                 if (done) {
                     if (MODE == 0) {
-                        if (a.terminal_obs) {
-                            float* to = a.terminal_obs + (size_t)i * HLX_OBS_DIM;
+                        if (O->terminal_obs) {
+                            float* to = O->terminal_obs + (size_t)i * HLX_OBS_DIM;
 #pragma unroll
                             for (int k = 0; k < HLX_OBS_DIM; ++k) to[k] = row[k];
                         }
-                        if (a.info.episode_return) a.info.episode_return[i] = ep_return;
-                        if (a.info.episode_length) a.info.episode_length[i] = steps;
+                        if (O->info.episode_return) O->info.episode_return[i] = ep_return;
+                        if (O->info.episode_length) O->info.episode_length[i] = steps;
                     }
                     // ---------------- spawn (environment.py:375-567): float64 draws cast to float32
-                    const KCold& k = *a.cold;
+                    const KCold& k = P->cold;
                     const bool rbuf = rnoise_buf;
                     double u[10];
                     if (rbuf) {
@@ -475,30 +554,37 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                         rng.normals4(RS_RESET_GVEL, f.x, f.y, f.z, w_); n_gv = to_d3(f);
                     }
                 }
+                STAMP2(2);  // close-up: draws selected
                 const V3 rel = mpos - ipos;
                 const float range = snorm3(rel);
                 bool on_det = !(range > c.radar_range);                             // :539
+                STAMP2(3);  // close-up: range
                 const V3 fwd = forward_vec(q);
+                STAMP2(4);  // close-up: forward vector
                 {
                     V3 tom = rel / (range + 1e-6f);                                 // :546
                     float beam_angle = acosf(clampf(sdot3(fwd, tom), -1.f, 1.f));   // :547
-                    if ((double)beam_angle > a.half_beam) on_det = false;           // :553 (float64 comparison)
+                    if ((double)beam_angle > P->cur.half_beam) on_det = false;           // :553 (float64 comparison)
                 }
+                STAMP2(5);  // close-up: beam angle (acosf)
                 if (on_det) {                                                       // :559-566
-                    float aq = (c.radar_quality * (1.0f - (range / c.radar_range) * 0.5f)) * a.on_rel;
+                    float aq = (c.radar_quality * (1.0f - (range / c.radar_range) * 0.5f)) * P->cur.on_rel;
                     if (n_on > aq) on_det = false;
                 }
+                STAMP2(6);  // close-up: Bernoulli
                 V3 d_on = rel;
                 bool d_on_det = on_det;
                 if (c.o_delay > 0) {                                                // :576-588 onboard delay ring
                     on_sample = make_float4(rel.x, rel.y, rel.z, on_det ? 1.f : 0.f);
                     d_on = v3(0.f, 0.f, 0.f); d_on_det = false;
                     if (pass == 0 && steps >= on_delay) {
-                        int slot = (int)((t + (unsigned long long)(o_cap - on_delay)) % (unsigned long long)o_cap);
-                        float4 s = a.oring[(size_t)slot * N + i];
+                        int slot = o_wslot - on_delay;                            // (t - on_delay) mod o_cap
+                        slot += (slot < 0) ? o_cap : 0;
+                        float4 s = oring[(size_t)slot * N + i];
                         d_on = v3(s.x, s.y, s.z); d_on_det = s.w != 0.f;
                     }
                 }
+                STAMP(8);   // onboard detection + onboard ring
                 // ---- ground radar (core.py:368-438)
                 bool g_det = false;
                 D3 g_pos = d3(0., 0., 0.);
@@ -515,7 +601,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     }
                     if (mpos.z < 50.f) g_det = false;                               // :409
                     if (g_det) {                                                    // :413-418
-                        float dpq = ((c.g_base_q * (1.0f - (grange / c.g_max_range) * 0.4f)) * c.weather) * a.g_rel;
+                        float dpq = ((c.g_base_q * (1.0f - (grange / c.g_max_range) * 0.4f)) * c.weather) * P->cur.g_rel;
                         if (n_g > dpq) g_det = false;
                         else {
                             // :422-429 float64 measurement (kept float64 through the delay ring: the Kalman
@@ -547,6 +633,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     }
                 }
                 const V3 d_gp = to_v3(d_gp64);
+                STAMP(9);   // ground radar + ground ring
                 // ---- datalink (core.py:440-474)
                 float datalink = 0.f;
                 if (HAS(HLX_F_GROUND)) {
@@ -569,6 +656,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                 }
                 if (pass == 0) det_bits = (d_on_det ? 32u : 0u) | (d_g_det ? 64u : 0u);
 
+                STAMP(10);  // datalink + fusion confidence
                 // ======================================================== core.py:693-1032 compute()
                 // measurement fusion + Kalman filter mirror the reference's dtype flow (float32 until a
                 // float64 ground measurement is absorbed, float64 afterwards): core.py:732-774, :91-116
@@ -622,6 +710,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                     }
                     have_track = kf_init;
                 }
+                STAMP(11);  // measurement fusion + Kalman filter
                 // ---- observation vector: pure outputs, ordinary fast float32 from here on
                 const float inv_mr = c.inv_max_range, inv_mv = c.inv_max_velocity;
                 if (have_track) {                                                   // :778-906
@@ -719,9 +808,11 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
                 }
                 row[24] = datalink;                                                 // :1027
                 row[25] = fusion;                                                   // :1030
+                STAMP(12);  // 26-D observation formulas -> LDS row
             }
         }
 
+        STAMP(13);  // observation passes (incl. loop exit)
         // ---------------------------------------------------------------------- store state + rings
         if (MODE == 0 || done) {
             packed = (uint32_t)steps | ((uint32_t)worsening << 13) | ((uint32_t)crossed << 25) |
@@ -740,44 +831,45 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
             A[G_KFP * 64] = make_float4(p_pp, p_pv, p_vp, p_vv);
             if (HAS(HLX_F_THRUST_LAG)) A[G_THRUST * 64] = make_float4(thrust_act.x, thrust_act.y, thrust_act.z, 0.f);
             if (HAS(HLX_F_DOMAIN_RAND)) A[G_MISC * 64] = make_float4(T0, dp.base_cd, dp.peak, 0.f);
-            if (c.o_delay > 0) a.oring[(size_t)(t % (unsigned long long)o_cap) * N + i] = on_sample;
+            if (c.o_delay > 0) oring[(size_t)o_wslot * N + i] = on_sample;
             if (HAS(HLX_F_GROUND) && c.g_delay > 0) {
-                float4* R = a.gring + ((size_t)(t % (unsigned long long)g_cap) * GROUND_RING_WORDS16) * N + i;
+                float4* R = gring + ((size_t)g_wslot * GROUND_RING_WORDS16) * N + i;
                 *reinterpret_cast<double2*>(R) = make_double2(g_sp.x, g_sp.y);
                 R[N] = make_float4(__int_as_float(__double2loint(g_sp.z)), __int_as_float(__double2hiint(g_sp.z)), g_sq, g_sflag);
                 R[2 * N] = g_s2;
             }
         }
         if (MODE == 0) {
-            a.reward[i] = reward;
-            a.term[i] = terminated ? 1 : 0;
-            a.trunc[i] = truncated ? 1 : 0;
-            if (a.info.distance) a.info.distance[i] = distance;
-            if (a.info.min_distance) a.info.min_distance[i] = min_distance;
-            if (a.info.fuel) a.info.fuel[i] = fuel;
-            if (a.info.flags)
-                a.info.flags[i] = (uint8_t)((intercepted ? 1u : 0u) | (hit_target ? 2u : 0u) | (fuze ? 4u : 0u) |
+            reward_out[i] = reward;
+            term_out[i] = terminated ? 1 : 0;
+            trunc_out[i] = truncated ? 1 : 0;
+            if (O->info.distance) O->info.distance[i] = distance;
+            if (O->info.min_distance) O->info.min_distance[i] = min_distance;
+            if (O->info.fuel) O->info.fuel[i] = fuel;
+            if (O->info.flags)
+                O->info.flags[i] = (uint8_t)((intercepted ? 1u : 0u) | (hit_target ? 2u : 0u) | (fuze ? 4u : 0u) |
                                             (clamped ? 8u : 0u) | (crossed ? 16u : 0u) | det_bits);
         }
     }
 
+    STAMP(14);      // state / ring / scalar outputs stored
     // -------------------------------------------------------------------------- done-mask compaction
-    if (MODE == 0 && a.done_idx) {
+    if (MODE == 0 && O->done_idx) {
         const unsigned long long m = __ballot(live && done);
         if (m) {
             int base = 0;
-            if (lane == 0) base = atomicAdd(a.done_cnt + (int)(t & 1ull), __popcll(m));
+            if (lane == 0) base = atomicAdd(P->done_cnt + (int)(t & 1ull), __popcll(m));
             base = __shfl(base, 0);
-            if (live && done) a.done_idx[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+            if (live && done) O->done_idx[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
         }
-        if (blockIdx.x == 0 && lane == 0) a.done_cnt[(int)((t + 1ull) & 1ull)] = 0;   // arm the other counter
+        if (blockIdx.x == 0 && lane == 0) P->done_cnt[(int)((t + 1ull) & 1ull)] = 0;   // arm the other counter
     }
 
     // -------------------------------------------------------------------------- observation tile -> [N][26]
-    if (a.obs) {
+    if (obs_out) {
         __syncthreads();
         const int rows = min(64, n - blockIdx.x * 64);
-        float* dst = a.obs + (size_t)blockIdx.x * 64 * HLX_OBS_DIM;
+        float* dst = obs_out + (size_t)blockIdx.x * 64 * HLX_OBS_DIM;
         if (MODE == 0) {
             if (rows == 64) {
                 const float4* src4 = reinterpret_cast<const float4*>(tile);
@@ -794,6 +886,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(const KArgs a) {
             for (int k = 0; k < HLX_OBS_DIM; ++k) dst[lane * HLX_OBS_DIM + k] = row[k];
         }
     }
+    STAMP(15);      // observation tile stored
 }
 
 }  // namespace

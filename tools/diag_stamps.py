@@ -1,0 +1,41 @@
+"""Where does a wave spend its life?  Runs the stamp-instrumented diagnostic build (libhlx_stamps.so) and
+prints the median per-segment share of the wave lifetime.  Shares only: the stamps' fences forbid overlaps the
+product kernel has, so this build's absolute run time is never quoted."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["HLX_LIBRARY"] = os.path.join(ROOT, "hlynr_intercept_amd", "libhlx_stamps.so")
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from hlynr_intercept_amd.scenarios import scenario_config
+from hlynr_intercept_amd.vec_env import HlynrVecEnv
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+physics = sys.argv[2] if len(sys.argv) > 2 else "base"
+env = HlynrVecEnv(scenario_config("medium", physics), num_envs=n, seed=1)
+env.reset_torch()
+lib = env._lib
+lib.hlx_debug_read_stamps.restype = C.c_int
+lib.hlx_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p]
+g = torch.Generator(device=env.device).manual_seed(0)
+names = ["entry->loads issued", "Philox block", "wait+unpack+clamp", "interceptor", "missile", "wind+termination",
+         "reward", "obs: onboard detection", "obs: ground radar", "obs: datalink+fusion", "obs: fusion+Kalman",
+         "obs: 26-D formulas", "obs: loop exit", "state stores", "compaction+tile store"]
+if os.environ.get("HLX_STAMP_LEVEL") == "2":
+    names = ["entry->loop top", "draw select", "rel+range", "forward_vec", "tom+acosf", "Bernoulli", "->reward stamp(n/a)",
+             "onboard ring etc", "obs: ground radar", "obs: datalink+fusion", "obs: fusion+Kalman", "obs: 26-D formulas",
+             "obs: loop exit", "state stores", "compaction+tile store"]
+acc = []
+for t in range(60):
+    a = torch.rand((n, 6), generator=g, device=env.device) * 2 - 1
+    env.step_torch(a)
+    if t >= 20:
+        buf = np.zeros(((n + 63) // 64, 16), np.uint64)
+        assert lib.hlx_debug_read_stamps(env._h, buf.ctypes.data) == 0
+        d = np.diff(buf[:, :16].astype(np.int64), axis=1)
+        acc.append(d)
+d = np.concatenate(acc)
+tot = d.sum(1)
+print(f"n={n} physics={physics}: median wave lifetime {np.median(tot):.0f} s_memtime ticks (100 MHz clock -> {np.median(tot)*10:.0f} ns)")
+for k, nm in enumerate(names[:d.shape[1]]):
+    print(f"  {nm:24s} median {np.median(d[:, k]):8.0f} ticks  share {100*np.median(d[:, k]/tot):5.1f}%")
+env.close()
