@@ -81,8 +81,41 @@ DEV double cos_small(double x) {
     p = __builtin_fma(x2, p, -0.5);
     return __builtin_fma(x2, p, 1.0);
 }
-// fast (non-mirrored) helpers for pure outputs
+// fast (non-mirrored) helpers for pure outputs and for detection decisions (a threshold compare tolerates an
+// ulp: it can only matter for an input that sits exactly on the boundary)
 DEV float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+// atan on [-1,1], Abramowitz & Stegun 4.4.49 (|err| <= 2e-8 in exact arithmetic, ~1e-7 in float32)
+DEV float atan_unit(float a) {
+    const float s = a * a;
+    float p = __builtin_fmaf(s, 0.0028662257f, -0.0161657367f);
+    p = __builtin_fmaf(s, p, 0.0429096138f);
+    p = __builtin_fmaf(s, p, -0.0752896400f);
+    p = __builtin_fmaf(s, p, 0.1065626393f);
+    p = __builtin_fmaf(s, p, -0.1420889944f);
+    p = __builtin_fmaf(s, p, 0.1999355085f);
+    p = __builtin_fmaf(s, p, -0.3333314528f);
+    return __builtin_fmaf(a * s, p, a);
+}
+DEV float fast_atan2(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float r = (mx > 0.f) ? atan_unit(mn * __builtin_amdgcn_rcpf(mx)) : 0.f;
+    r = (ay > ax) ? 1.5707963267948966f - r : r;
+    r = (x < 0.f) ? 3.141592653589793f - r : r;
+    return copysignf(r, y);
+}
+// asin on [-1,1], Abramowitz & Stegun 4.4.46 (|err| <= 2e-8 exact, ~3e-7 float32)
+DEV float fast_asin(float x) {
+    const float ax = fminf(fabsf(x), 1.0f);
+    float p = __builtin_fmaf(ax, -0.0012624911f, 0.0066700901f);
+    p = __builtin_fmaf(ax, p, -0.0170881256f);
+    p = __builtin_fmaf(ax, p, 0.0308918810f);
+    p = __builtin_fmaf(ax, p, -0.0501743046f);
+    p = __builtin_fmaf(ax, p, 0.0889789874f);
+    p = __builtin_fmaf(ax, p, -0.2145988016f);
+    p = __builtin_fmaf(ax, p, 1.5707963050f);
+    return copysignf(1.5707963267948966f - __builtin_sqrtf(1.0f - ax) * p, x);
+}
 DEV float fdot(V3 a, V3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
 DEV float fnorm(V3 a) { return __builtin_sqrtf(fdot(a, a)); }
 
@@ -207,9 +240,9 @@ DEV D3 nan_guard(D3 a, double lim) {
 struct Quat {
     float w, x, y, z;
 };
-DEV V3 forward_vec(Quat q) {   // core.py:1143-1152
+DEV V3 forward_vec(Quat q) {   // core.py:1143-1152 (feeds a threshold compare and pure outputs: fast float32)
     V3 f = v3(2.f * (q.x * q.z + q.w * q.y), 2.f * (q.y * q.z - q.w * q.x), 1.f - 2.f * (q.x * q.x + q.y * q.y));
-    return f / (snorm3(f) + 1e-6f);
+    return f * __builtin_amdgcn_rcpf(fnorm(f) + 1e-6f);
 }
 DEV V3 right_vec(Quat q) {     // core.py:1155-1164
     V3 f = v3(1.f - 2.f * (q.y * q.y + q.z * q.z), 2.f * (q.x * q.y + q.w * q.z), 2.f * (q.x * q.z - q.w * q.y));

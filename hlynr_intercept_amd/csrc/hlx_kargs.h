@@ -52,10 +52,11 @@ struct KCfg {
     double wind_var;
     float bl_height, bl_prof, ti_low, ti_mid, ti_high;
     double turb_lp, gust_scale, inv_tau;
-    float kill_radius, radar_quality, radar_range;
+    float kill_radius, radar_quality, radar_range, inv_radar_range;
     double radar_quality64;
-    float ground_pos[3], g_max_range, g_base_q, max_datalink, weather;
-    double g_min_elev, g_max_elev, g_range_acc, g_vel_acc, packet_loss;
+    float ground_pos[3], g_max_range, inv_g_max_range, g_base_q, max_datalink, inv_max_datalink, weather;
+    float sin_min_elev, sin_max_elev;   // elevation window as sines (asin is monotonic)
+    double g_range_acc, g_vel_acc, packet_loss;
     float q11, q12, q22;      // Kalman process noise (core.py:34-42, q = 5^2)
 };
 // Spawn / domain-randomisation ("cold") constants: only finished environments read them, so they live
@@ -87,12 +88,24 @@ struct KOpt {              // optional caller buffers (re-uploaded only when the
 };
 struct KCur {              // curriculum scalars in force (re-uploaded when hlx_set_global_step changes them)
     double half_beam;
-    float radius, on_rel, g_rel, pad;
+    float radius, on_rel, g_rel;
+    float cos_half_beam;   // beam test on the cosine: arccos(x) > hb <=> x < cos(hb); -2 when hb >= pi
 };
-struct KParams {           // device-resident
+// The hot part {c, cur, opt} is at most 512 B = 128 dwords: at kernel entry lane l loads dwords l and 64 + l
+// (two coalesced vector loads, in flight with the state loads), and every constant is then a v_readlane away --
+// no scalar load, hence no s_waitcnt, anywhere on the per-step path (scalar loads return out of order, so each
+// lazily placed one costs a full `s_waitcnt lgkmcnt(0)` round trip that the lone wave of a SIMD cannot hide;
+// round-1 stamps attributed about a third of the wave lifetime to some thirty of them).
+struct KHot {
     KCfg c;
     KCur cur;
     KOpt opt;
+};
+static_assert(sizeof(KHot) <= 512, "hot parameter block must fit two dwords per lane");
+static_assert(sizeof(KHot) % 4 == 0, "hot parameter block is read dword-wise");
+struct KParams {           // device-resident
+    KHot hot;
+    char hot_pad[512 - sizeof(KHot)];   // the entry loads always read 512 B
     KCold cold;
     float4* gring;         // [g_delay+1][GROUND_RING_WORDS16][N]
     float4* oring;         // [o_cap][N]

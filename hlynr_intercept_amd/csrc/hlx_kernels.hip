@@ -67,30 +67,19 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
     float* __restrict__ obs_out, float* __restrict__ reward_out, uint8_t* __restrict__ term_out,
     uint8_t* __restrict__ trunc_out) {
     __shared__ __attribute__((aligned(16))) float tile[64 * HLX_OBS_DIM];
-    const uint32_t FL = (SPEC & KF_DYNAMIC) ? P->c.flags : SPEC;
+    const uint32_t FL = (SPEC & KF_DYNAMIC) ? P->hot.c.flags : SPEC;   // generic variant only: one scalar load
     const int lane = threadIdx.x;
     const int i = blockIdx.x * 64 + lane;
     const bool live = i < n;
     const int g_rslot = (int)(slots & 15u), g_wslot = (int)((slots >> 4) & 15u), o_wslot = (int)((slots >> 8) & 15u);
     const int g_planes = (int)((slots >> 12) & 15u), o_planes = (int)((slots >> 16) & 15u);   // preloaded: no *P needed
-    const KOpt* O = &P->opt;
-    const KCfg& c = P->c;
     float* row = tile + lane * HLX_OBS_DIM;
     bool done = false;
+    int32_t* done_idx_out = nullptr;   // optional compaction output (read from the hot block inside the live section)
 
     STAMP(0);
-    // The scalar data cache is invalidated at every dispatch, and the compiler loads config fields lazily, one
-    // line at a time, right where they are first used: each first touch of a 64-byte line of *P would stall the
-    // lone wave of this SIMD for an L2 round trip.  Touch every line of the hot block now (the loads fly together
-    // with the state loads below); `cfg_touch` is consumed after the Philox block, by when they have landed.
-    constexpr int kTouch = (int)((offsetof(KParams, cold) + 63) / 64);
-    static_assert(kTouch <= 8, "hot part of KParams grew: extend the touch list");
-    uint32_t cfg_touch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    {
-        const uint32_t* pw = reinterpret_cast<const uint32_t*>(P);
-#pragma unroll
-        for (int k = 0; k < kTouch; ++k) cfg_touch[k] = pw[k * 16];   // no arithmetic on them: that would wait here
-    }
+    // Hot parameter block: two coalesced dword loads per lane now, v_readlane per constant later (hlx_kargs.h).
+    uint32_t hotw0 = reinterpret_cast<const uint32_t*>(P)[lane], hotw1 = reinterpret_cast<const uint32_t*>(P)[64 + lane];
     // State loads are issued before anything else, for every lane: the arena is padded to whole 64-env blocks,
     // its pointer arrives preloaded in SGPRs, and nothing here depends on the rest of the kernel arguments.
     // arena layout: [workgroup][group][64 lanes] of 16-byte words -> one contiguous ~11 KiB chunk per wave,
@@ -103,10 +92,14 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
     float4 g_ipos = A[G_IPOS * 64], g_ivel = A[G_IVEL * 64], g_quat = A[G_QUAT * 64], g_mpos = A[G_MPOS * 64];
     float4 g_mvel = A[G_MVEL * 64], g_w1 = A[G_W1 * 64], g_kfp = A[G_KFP * 64];
     double2 g_w0 = AD[G_W0 * 64], g_kf0 = AD[G_KF0 * 64], g_kf1 = AD[G_KF1 * 64], g_kf2 = AD[G_KF2 * 64];
-    float4 g_thr = make_float4(0.f, 0.f, 0.f, 0.f), g_misc = make_float4(288.15f, 0.3f, P->c.peak, 0.f);
+    float4 g_thr = make_float4(0.f, 0.f, 0.f, 0.f), g_misc = make_float4(288.15f, 0.3f, 0.f, 0.f);
     if (HAS(HLX_F_THRUST_LAG)) g_thr = A[G_THRUST * 64];
     if (HAS(HLX_F_DOMAIN_RAND)) g_misc = A[G_MISC * 64];
-    if (live) {
+    // Everything down to the construction of `hot` runs with ALL lanes enabled: the constants are fetched with
+    // cross-lane reads (v_readlane), so the lanes that hold them must have executed their loads even in a partial
+    // tail block; padding lanes use the last live environment's addresses and their results are discarded.
+    const int ic = live ? i : (n - 1);
+    {
         const size_t N = (size_t)n;
         // rings live right behind the (64-padded) arena in the same allocation: addresses need only preloaded values
         float4* const gring = arena + (size_t)((n + 63) >> 6) * (N_GROUPS * 64);     // [g_delay+1][3][N]
@@ -115,22 +108,22 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
         double2 gr0 = make_double2(0., 0.);
         float4 gr1 = make_float4(0.f, 0.f, 0.f, 0.f), gr2 = gr1;
         if (MODE == 0) {
-            const float2* ap = reinterpret_cast<const float2*>(actions + (size_t)i * HLX_ACT_DIM);
+            const float2* ap = reinterpret_cast<const float2*>(actions + (size_t)ic * HLX_ACT_DIM);
             a01 = ap[0]; a23 = ap[1]; a45 = ap[2];
             if (HAS(HLX_F_GROUND)) {   // unconditional when the station exists (the host always allocates >= 1 slot):
                                        // a runtime guard here would put a register merge, i.e. a wait, in front of Philox
-                const float4* R = gring + ((size_t)g_rslot * GROUND_RING_WORDS16) * N + i;   // slot (t - g_delay) mod cap
+                const float4* R = gring + ((size_t)g_rslot * GROUND_RING_WORDS16) * N + ic;   // slot (t - g_delay) mod cap
                 gr0 = *reinterpret_cast<const double2*>(R); gr1 = R[N]; gr2 = R[2 * N];
             }
         }
 
         STAMP(1);   // all loads issued
-        const bool noise_buf = NOISE && O->step_noise != nullptr;
-        const bool rnoise_buf = NOISE && O->reset_noise != nullptr;
+        const bool noise_buf = NOISE && P->hot.opt.step_noise != nullptr;    // parity instantiation only
+        const bool rnoise_buf = NOISE && P->hot.opt.reset_noise != nullptr;
         const unsigned long long gid = (unsigned long long)(env_offset + i);
         Rng rng{uint2{(uint32_t)seed, (uint32_t)(seed >> 32)}, (uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)t, (uint32_t)(t >> 32)};
-        const double* SN = NOISE ? O->step_noise + i : nullptr;   // slot-major [slot][N] (float64: parity mode replays the reference's draws)
-        const double* RN = NOISE ? O->reset_noise + i : nullptr;
+        const double* SN = NOISE ? P->hot.opt.step_noise + ic : nullptr;   // slot-major [slot][N] (float64: parity mode replays the reference's draws)
+        const double* RN = NOISE ? P->hot.opt.reset_noise + ic : nullptr;
 
         // ------------------------------------------------------------------ this step's random draws
         // (five independent Philox chains in one straight-line block: instruction-level parallelism for
@@ -176,10 +169,22 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
         PIN2(a01); PIN2(a23); PIN2(a45); PIN2(gr0); PIN4(gr1); PIN4(gr2);
 #undef PIN4
 #undef PIN2
-        // config lines are resident in the scalar cache, and the output pointers of the kernarg tail have landed
-        asm volatile("" ::"s"(cfg_touch[0]), "s"(cfg_touch[1]), "s"(cfg_touch[2]), "s"(cfg_touch[3]), "s"(cfg_touch[4]),
-                     "s"(cfg_touch[5]), "s"(cfg_touch[6]), "s"(cfg_touch[7]), "s"(obs_out), "s"(reward_out), "s"(term_out),
-                     "s"(trunc_out));
+        // the output pointers of the kernarg tail have landed by now
+        asm volatile("" ::"s"(obs_out), "s"(reward_out), "s"(term_out), "s"(trunc_out));
+        // hot parameter block -> uniform registers, one v_readlane per dword that is actually used
+        asm volatile("" : "+v"(hotw0), "+v"(hotw1));
+        KHot hot;
+        {
+            uint32_t w[sizeof(KHot) / 4];
+#pragma unroll
+            for (int k = 0; k < (int)(sizeof(KHot) / 4); ++k) w[k] = __builtin_amdgcn_readlane(k < 64 ? hotw0 : hotw1, k & 63);
+            __builtin_memcpy(&hot, w, sizeof(KHot));
+        }
+        const KCfg& c = hot.c;
+        const KOpt* O = &hot.opt;
+        if (!HAS(HLX_F_DOMAIN_RAND)) g_misc.z = c.peak;
+        done_idx_out = O->done_idx;
+        if (live) {   // ============================== per-environment work, live lanes only ==============================
         STAMP(2);   // Philox block done (loads still in flight)
         V3 ipos = v3(g_ipos.x, g_ipos.y, g_ipos.z), ivel = v3(g_ivel.x, g_ivel.y, g_ivel.z);
         Quat q = Quat{g_quat.x, g_quat.y, g_quat.z, g_quat.w};
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
             V3 rel = mpos - ipos;
             distance = snorm3(rel);
             if (HAS(HLX_F_PROX_FUZE)) intercepted = distance < c.kill_radius;       // :700-703
-            else intercepted = distance < P->cur.radius;
+            else intercepted = distance < hot.cur.radius;
             min_distance = (distance < min_distance) ? distance : min_distance;     // :706
             if (intercepted) crossed = true;                                        // :709-710
             if (HAS(HLX_F_PROX_FUZE) && min_distance < c.kill_radius) { fuze = true; intercepted = true; } // :715-717
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                     float md = min_distance;
                     if (crossed) {
                         reward = 3000.f;
-                        if (md < P->cur.radius) reward = reward + ((P->cur.radius - md) / P->cur.radius) * 1000.f;
+                        if (md < hot.cur.radius) reward = reward + ((hot.cur.radius - md) / hot.cur.radius) * 1000.f;
                         reward = reward + expf(divc(-md, 1.0 / 25.0)) * 500.f;
                         reward = reward + expf(divc(-md, 1.0 / 10.0)) * 1000.f;
                         reward = reward + expf(divc(-md, 1.0 / 3.0)) * 500.f;
@@ -561,14 +566,13 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 STAMP2(3);  // close-up: range
                 const V3 fwd = forward_vec(q);
                 STAMP2(4);  // close-up: forward vector
-                {
-                    V3 tom = rel / (range + 1e-6f);                                 // :546
-                    float beam_angle = acosf(clampf(sdot3(fwd, tom), -1.f, 1.f));   // :547
-                    if ((double)beam_angle > P->cur.half_beam) on_det = false;           // :553 (float64 comparison)
+                {   // :546-553  arccos(clip(fwd . to_missile)) > half_beam  <=>  clip(fwd . to_missile) < cos(half_beam)
+                    const float cb = clampf(fdot(fwd, rel) * __builtin_amdgcn_rcpf(range + 1e-6f), -1.f, 1.f);
+                    if (cb < hot.cur.cos_half_beam) on_det = false;
                 }
                 STAMP2(5);  // close-up: beam angle (acosf)
                 if (on_det) {                                                       // :559-566
-                    float aq = (c.radar_quality * (1.0f - (range / c.radar_range) * 0.5f)) * P->cur.on_rel;
+                    float aq = (c.radar_quality * (1.0f - (range * c.inv_radar_range) * 0.5f)) * hot.cur.on_rel;
                     if (n_on > aq) on_det = false;
                 }
                 STAMP2(6);  // close-up: Bernoulli
@@ -593,15 +597,15 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 const V3 gp = v3(c.ground_pos[0], c.ground_pos[1], c.ground_pos[2]);
                 if (HAS(HLX_F_GROUND)) {
                     V3 g2m = mpos - gp;
-                    float grange = snorm3(g2m);
+                    float grange = fnorm(g2m);
                     g_det = !(grange > c.g_max_range);                              // :396
-                    if (g_det && grange > 1e-6f) {                                  // :401-406 (float64 comparisons)
-                        double el = (double)asinf(clampf(g2m.z / grange, -1.f, 1.f));
-                        if (el < c.g_min_elev || el > c.g_max_elev) g_det = false;
+                    if (g_det && grange > 1e-6f) {                                  // :401-406  asin is monotonic: compare sines
+                        const float se = clampf(g2m.z * __builtin_amdgcn_rcpf(grange), -1.f, 1.f);
+                        if (se < c.sin_min_elev || se > c.sin_max_elev) g_det = false;
                     }
                     if (mpos.z < 50.f) g_det = false;                               // :409
                     if (g_det) {                                                    // :413-418
-                        float dpq = ((c.g_base_q * (1.0f - (grange / c.g_max_range) * 0.4f)) * c.weather) * P->cur.g_rel;
+                        float dpq = ((c.g_base_q * (1.0f - (grange * c.inv_g_max_range) * 0.4f)) * c.weather) * hot.cur.g_rel;
                         if (n_g > dpq) g_det = false;
                         else {
                             // :422-429 float64 measurement (kept float64 through the delay ring: the Kalman
@@ -637,10 +641,10 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 // ---- datalink (core.py:440-474)
                 float datalink = 0.f;
                 if (HAS(HLX_F_GROUND)) {
-                    float lr = snorm3(ipos - gp);
+                    float lr = fnorm(ipos - gp);
                     if (!(lr > c.max_datalink) && !(n_dl < c.packet_loss)) {
-                        float x = lr / c.max_datalink;
-                        float vr = divc(snorm3(ivel), 1.0 / 1000.0);
+                        float x = lr * c.inv_max_datalink;
+                        float vr = fnorm(ivel) * 0.001f;
                         float dop = (0.3f < vr) ? (float)(1.0 - 0.3) : (1.0f - vr);
                         datalink = clampf(((1.0f - x * x) * dop) * 0.95f, 0.f, 1.f);
                     }
@@ -777,9 +781,9 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 if (HAS(HLX_F_OBS_BODY) || HAS(HLX_F_OBS_LOS)) { row[9] = 0.f; row[10] = 0.f; row[11] = 0.f; } // :967-970
                 else {                                                              // :973-974, core.py:1103-1121
                     const float inv_pi = 0.3183098861837907f;
-                    row[9] = atan2f(2.f * (q.w * q.x + q.y * q.z), 1.f - 2.f * (q.x * q.x + q.y * q.y)) * inv_pi;
-                    row[10] = asinf(clampf(2.f * (q.w * q.y - q.z * q.x), -1.f, 1.f)) * inv_pi;
-                    row[11] = atan2f(2.f * (q.w * q.z + q.x * q.y), 1.f - 2.f * (q.y * q.y + q.z * q.z)) * inv_pi;
+                    row[9] = fast_atan2(2.f * (q.w * q.x + q.y * q.z), 1.f - 2.f * (q.x * q.x + q.y * q.y)) * inv_pi;
+                    row[10] = fast_asin(clampf(2.f * (q.w * q.y - q.z * q.x), -1.f, 1.f)) * inv_pi;
+                    row[11] = fast_atan2(2.f * (q.w * q.z + q.x * q.y), 1.f - 2.f * (q.y * q.y + q.z * q.z)) * inv_pi;
                 }
                 row[12] = clampf(fuel * 0.01f, 0.f, 1.f);                           // :977
                 if (d_g_det && datalink > 0.1f) {                                   // :980-1018
@@ -850,17 +854,18 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 O->info.flags[i] = (uint8_t)((intercepted ? 1u : 0u) | (hit_target ? 2u : 0u) | (fuze ? 4u : 0u) |
                                             (clamped ? 8u : 0u) | (crossed ? 16u : 0u) | det_bits);
         }
+        }   // if (live)
     }
 
     STAMP(14);      // state / ring / scalar outputs stored
     // -------------------------------------------------------------------------- done-mask compaction
-    if (MODE == 0 && O->done_idx) {
+    if (MODE == 0 && done_idx_out) {
         const unsigned long long m = __ballot(live && done);
         if (m) {
             int base = 0;
             if (lane == 0) base = atomicAdd(P->done_cnt + (int)(t & 1ull), __popcll(m));
             base = __shfl(base, 0);
-            if (live && done) O->done_idx[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+            if (live && done) done_idx_out[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
         }
         if (blockIdx.x == 0 && lane == 0) P->done_cnt[(int)((t + 1ull) & 1ull)] = 0;   // arm the other counter
     }

@@ -2,7 +2,7 @@
 import re, sys, collections
 txt = open(sys.argv[1]).read().split('\n')
 key = sys.argv[2]
-start = next(i for i, l in enumerate(txt) if l.startswith('_ZN') and key in l and l.rstrip().split(':')[0].endswith('E'))
+start = next(i for i, l in enumerate(txt) if l.startswith('_ZN') and key in l and ':' in l)
 end = next(i for i in range(start + 1, len(txt)) if txt[i].startswith('.Lfunc_end') or txt[i].strip().startswith('.end_amdhsa_kernel') or txt[i].startswith('\t.section'))
 lines = [l.strip() for l in txt[start:end] if l.startswith('\t') and not l.strip().startswith(('.', ';'))]
 ops = collections.Counter(l.split()[0] for l in lines)
