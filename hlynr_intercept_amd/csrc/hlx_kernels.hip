@@ -40,7 +40,7 @@ namespace {
         __builtin_amdgcn_sched_barrier(0);                                                             \
         unsigned long long t_;                                                                         \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                      \
-        if (lane == 0 && P->stamps) P->stamps[(size_t)blockIdx.x * 16 + (k)] = t_;                       \
+        if (lane == 0) stamp_base[(k)] = t_;                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                             \
     } while (0)
 // HLX_STAMPS=1: coarse map of the whole wave; HLX_STAMPS=2: slots 1..6 re-used for a close-up of one segment
@@ -77,6 +77,10 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
     bool done = false;
     int32_t* done_idx_out = nullptr;   // optional compaction output (read from the hot block inside the live section)
 
+#ifdef HLX_STAMPS
+    unsigned long long* stamp_base = P->stamps + (size_t)blockIdx.x * 16;   // fetched once: a per-stamp scalar load
+    asm volatile("" : "+s"(stamp_base));                                     // would charge every segment ~1k cycles
+#endif
     STAMP(0);
     // Hot parameter block: two coalesced dword loads per lane now, v_readlane per constant later (hlx_kargs.h).
     uint32_t hotw0 = reinterpret_cast<const uint32_t*>(P)[lane], hotw1 = reinterpret_cast<const uint32_t*>(P)[64 + lane];
@@ -89,9 +93,10 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
     // ------------------------------------------------------------------ issue every load up front
     // (state groups, action row, the delayed ground-ring sample whose slot depends only on the global
     // clock); the Philox draws below do not depend on them and run while the loads are in flight.
+    // issue order = order of need: the integrator's groups first, the Kalman filter's (needed ~5k cycles later) last
     float4 g_ipos = A[G_IPOS * 64], g_ivel = A[G_IVEL * 64], g_quat = A[G_QUAT * 64], g_mpos = A[G_MPOS * 64];
-    float4 g_mvel = A[G_MVEL * 64], g_w1 = A[G_W1 * 64], g_kfp = A[G_KFP * 64];
-    double2 g_w0 = AD[G_W0 * 64], g_kf0 = AD[G_KF0 * 64], g_kf1 = AD[G_KF1 * 64], g_kf2 = AD[G_KF2 * 64];
+    float4 g_mvel = A[G_MVEL * 64], g_w1 = A[G_W1 * 64];
+    double2 g_w0 = AD[G_W0 * 64];
     float4 g_thr = make_float4(0.f, 0.f, 0.f, 0.f), g_misc = make_float4(288.15f, 0.3f, 0.f, 0.f);
     if (HAS(HLX_F_THRUST_LAG)) g_thr = A[G_THRUST * 64];
     if (HAS(HLX_F_DOMAIN_RAND)) g_misc = A[G_MISC * 64];
@@ -116,6 +121,8 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 gr0 = *reinterpret_cast<const double2*>(R); gr1 = R[N]; gr2 = R[2 * N];
             }
         }
+        float4 g_kfp = A[G_KFP * 64];
+        double2 g_kf0 = AD[G_KF0 * 64], g_kf1 = AD[G_KF1 * 64], g_kf2 = AD[G_KF2 * 64];
 
         STAMP(1);   // all loads issued
         const bool noise_buf = NOISE && P->hot.opt.step_noise != nullptr;    // parity instantiation only
@@ -162,13 +169,11 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
         // cold-start latency BEFORE doing the one piece of work that needs no memory.
 #define PIN4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
 #define PIN2(v) asm volatile("" : "+v"((v).x), "+v"((v).y))
-        PIN4(g_ipos); PIN4(g_ivel); PIN4(g_quat); PIN4(g_mpos); PIN4(g_mvel); PIN4(g_w1); PIN4(g_kfp);
-        PIN2(g_w0); PIN2(g_kf0); PIN2(g_kf1); PIN2(g_kf2);
+        PIN4(g_ipos); PIN4(g_ivel); PIN4(g_quat); PIN4(g_mpos); PIN4(g_mvel); PIN4(g_w1); PIN2(g_w0);
         if (HAS(HLX_F_THRUST_LAG)) PIN4(g_thr);
         if (HAS(HLX_F_DOMAIN_RAND)) PIN4(g_misc);
-        PIN2(a01); PIN2(a23); PIN2(a45); PIN2(gr0); PIN4(gr1); PIN4(gr2);
-#undef PIN4
-#undef PIN2
+        PIN2(a01); PIN2(a23); PIN2(a45);
+        // (the Kalman / ring registers are released further down, right before the observation section)
         // the output pointers of the kernarg tail have landed by now
         asm volatile("" ::"s"(obs_out), "s"(reward_out), "s"(term_out), "s"(trunc_out));
         // hot parameter block -> uniform registers, one v_readlane per dword that is actually used
@@ -196,8 +201,6 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
         int steps = (int)(packed & 0x1FFFu), worsening = (int)((packed >> 13) & 0xFFFu);
         bool crossed = (packed >> 25) & 1u, kf_init = (packed >> 26) & 1u, kf_x64 = (packed >> 27) & 1u;
         int on_delay = (int)(packed >> 28);
-        D3 kxp = d3(g_kf0.x, g_kf0.y, g_kf1.x), kxv = d3(g_kf1.y, g_kf2.x, g_kf2.y);
-        float p_pp = g_kfp.x, p_pv = g_kfp.y, p_vp = g_kfp.z, p_vv = g_kfp.w;
         V3 thrust_act = v3(g_thr.x, g_thr.y, g_thr.z);
         float T0 = g_misc.x;
         DragParams dp{c.subsonic, c.supersonic, c.mach_span, g_misc.z, g_misc.y, c.cd_super};
@@ -437,6 +440,24 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
         }
 
         STAMP(7);   // reward
+        // ---------------------------------------------------------------------- early scalar outputs
+        // The step's scalar outputs go out now, while ~5k cycles of observation math follow.  (Storing the
+        // integrator's state groups here as well was measured: +0.5 us/step at 65 536 envs -- the stores
+        // contend with the tail of the entry loads -- so the state groups stay in the final store section.)
+        if (MODE == 0) {
+            reward_out[i] = reward;
+            term_out[i] = terminated ? 1 : 0;
+            trunc_out[i] = truncated ? 1 : 0;
+            if (O->info.distance) O->info.distance[i] = distance;
+            if (O->info.min_distance) O->info.min_distance[i] = min_distance;
+            if (O->info.fuel) O->info.fuel[i] = fuel;
+        }
+        // Kalman / ring registers become visible here (their loads were issued last, at kernel entry)
+        PIN4(g_kfp); PIN2(g_kf0); PIN2(g_kf1); PIN2(g_kf2); PIN2(gr0); PIN4(gr1); PIN4(gr2);
+#undef PIN4
+#undef PIN2
+        D3 kxp = d3(g_kf0.x, g_kf0.y, g_kf1.x), kxv = d3(g_kf1.y, g_kf2.x, g_kf2.y);
+        float p_pp = g_kfp.x, p_pv = g_kfp.y, p_vp = g_kfp.z, p_vv = g_kfp.w;
         // ---------------------------------------------------------------------- observation (+ auto-reset)
         // pass 0: observation of the stepped state.  pass 1 (only if some lane of the wave finished):
         // finished lanes respawn (environment.py:353-603) and build their first observation.
@@ -449,8 +470,13 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
         for (int pass = (MODE == 0 ? 0 : 1); pass < 2; ++pass) {
             STAMP2(1);  // close-up: loop top
             const bool act = (pass == 0) || done;
+            // `rsalt` is an opaque zero defined inside the respawn pass: the respawn draws are pure functions of
+            // loop-invariant values, and without it the optimiser hoists all six Philox chains (and the float64
+            // spawn trigonometry) out of the loop, i.e. executes them on EVERY step for every environment.
+            uint32_t rsalt = 0;
             if (pass == 1) {
                 if (__ballot(done) == 0ull) break;
+                asm volatile("" : "+v"(rsalt));
                 if (done) {
                     if (MODE == 0) {
                         if (O->terminal_obs) {
@@ -469,7 +495,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
 #pragma unroll
                         for (int k = 0; k < 10; ++k) u[k] = RN[k * N];
                     } else {
-                        uint4 x0 = rng.raw(RS_RESET_U0), x1 = rng.raw(RS_RESET_U1), x2 = rng.raw(RS_RESET_U2);
+                        uint4 x0 = rng.raw(RS_RESET_U0 + rsalt), x1 = rng.raw(RS_RESET_U1 + rsalt), x2 = rng.raw(RS_RESET_U2 + rsalt);
                         u[0] = u01(x0.x); u[1] = u01(x0.y); u[2] = u01(x0.z); u[3] = u01(x0.w);
                         u[4] = u01(x1.x); u[5] = u01(x1.y); u[6] = u01(x1.z); u[7] = u01(x1.w);
                         u[8] = u01(x2.x); u[9] = u01(x2.y);
@@ -520,8 +546,8 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                         else {
                             // draws 1..4 of the 13 (the others never reach the path): temperature, drag, mach, delay
                             float z0_, f1, f2, f3, f4, z1_, z2_, z3_;
-                            rng.normals4(RS_DR0, z0_, f1, f2, f3);
-                            rng.normals4(RS_DR1, f4, z1_, z2_, z3_);
+                            rng.normals4(RS_DR0 + rsalt, z0_, f1, f2, f3);
+                            rng.normals4(RS_DR1 + rsalt, f4, z1_, z2_, z3_);
                             zt = f1; zd = f2; zm = f3; zs = f4;
                         }
                         auto mult = [](double var, double z) { return fmin(fmax(1.0 + var * z, 0.1), 3.0); };
@@ -552,11 +578,11 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                         n_on = (float)B[0]; n_g = (float)B[1 * N]; n_gp = d3(B[2 * N], B[3 * N], B[4 * N]);
                         n_gv = d3(B[5 * N], B[6 * N], B[7 * N]); n_dl = B[8 * N];
                     } else {
-                        const uint4 x = rng.raw(RS_RESET_OBS_U);
+                        const uint4 x = rng.raw(RS_RESET_OBS_U + rsalt);
                         n_on = u01(x.x); n_g = u01(x.y); n_dl = (double)u01(x.z);
                         V3 f; float w_;
-                        rng.normals4(RS_RESET_GPOS, f.x, f.y, f.z, w_); n_gp = to_d3(f);
-                        rng.normals4(RS_RESET_GVEL, f.x, f.y, f.z, w_); n_gv = to_d3(f);
+                        rng.normals4(RS_RESET_GPOS + rsalt, f.x, f.y, f.z, w_); n_gp = to_d3(f);
+                        rng.normals4(RS_RESET_GVEL + rsalt, f.x, f.y, f.z, w_); n_gv = to_d3(f);
                     }
                 }
                 STAMP2(2);  // close-up: draws selected
@@ -827,13 +853,13 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
             A[G_MPOS * 64] = make_float4(mpos.x, mpos.y, mpos.z, min_distance);
             A[G_MVEL * 64] = make_float4(mvel.x, mvel.y, mvel.z, last_distance);
             AD[G_W0 * 64] = make_double2(wind.x, wind.y);
+            if (HAS(HLX_F_THRUST_LAG)) A[G_THRUST * 64] = make_float4(thrust_act.x, thrust_act.y, thrust_act.z, 0.f);
             A[G_W1 * 64] = make_float4(__int_as_float(__double2loint(wind.z)), __int_as_float(__double2hiint(wind.z)),
                                       __uint_as_float(packed), ep_return);
             AD[G_KF0 * 64] = make_double2(kxp.x, kxp.y);
             AD[G_KF1 * 64] = make_double2(kxp.z, kxv.x);
             AD[G_KF2 * 64] = make_double2(kxv.y, kxv.z);
             A[G_KFP * 64] = make_float4(p_pp, p_pv, p_vp, p_vv);
-            if (HAS(HLX_F_THRUST_LAG)) A[G_THRUST * 64] = make_float4(thrust_act.x, thrust_act.y, thrust_act.z, 0.f);
             if (HAS(HLX_F_DOMAIN_RAND)) A[G_MISC * 64] = make_float4(T0, dp.base_cd, dp.peak, 0.f);
             if (c.o_delay > 0) oring[(size_t)o_wslot * N + i] = on_sample;
             if (HAS(HLX_F_GROUND) && c.g_delay > 0) {
@@ -844,12 +870,6 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
             }
         }
         if (MODE == 0) {
-            reward_out[i] = reward;
-            term_out[i] = terminated ? 1 : 0;
-            trunc_out[i] = truncated ? 1 : 0;
-            if (O->info.distance) O->info.distance[i] = distance;
-            if (O->info.min_distance) O->info.min_distance[i] = min_distance;
-            if (O->info.fuel) O->info.fuel[i] = fuel;
             if (O->info.flags)
                 O->info.flags[i] = (uint8_t)((intercepted ? 1u : 0u) | (hit_target ? 2u : 0u) | (fuze ? 4u : 0u) |
                                             (clamped ? 8u : 0u) | (crossed ? 16u : 0u) | det_bits);
@@ -879,11 +899,13 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
             if (rows == 64) {
                 const float4* src4 = reinterpret_cast<const float4*>(tile);
                 float4* dst4 = reinterpret_cast<float4*>(dst);
+                float4 v[7];   // all LDS reads first (one wait), then the stores
 #pragma unroll
-                for (int r = 0; r < 7; ++r) {
-                    int j = lane + 64 * r;
-                    if (j < 64 * HLX_OBS_DIM / 4) dst4[j] = src4[j];
-                }
+                for (int r = 0; r < 6; ++r) v[r] = src4[lane + 64 * r];
+                v[6] = (lane < 64 * HLX_OBS_DIM / 4 - 384) ? src4[lane + 384] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int r = 0; r < 6; ++r) dst4[lane + 64 * r] = v[r];
+                if (lane < 64 * HLX_OBS_DIM / 4 - 384) dst4[lane + 384] = v[6];
             } else {
                 for (int j = lane; j < rows * HLX_OBS_DIM; j += 64) dst[j] = tile[j];
             }
