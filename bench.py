@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--physics", default="base", choices=["base", "v2dr"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused", type=int, default=64,
+                    help="also time the fused rollout (this many steps per launch, state held on-chip); 0 = skip")
     args = ap.parse_args()
 
     import torch
@@ -134,6 +136,25 @@ def main():
     bytes_per_launch = BYTES_PER_ENV_STEP[args.physics] * n
     achieved = bytes_per_launch / (kern_us * 1e-6) / 1e9 if launches else 0.0
 
+    # SURVEY.md 8(d) caveat: the T-step persistent number beside the one-launch-per-step headline
+    fused = None
+    if args.fused > 1:
+        env.set_rollout_fused(args.fused)
+        env.rollout_torch(tape[:min(W, K) or 1], out_slots)
+        sync_all()
+        env.profile(True)
+        t0 = time.perf_counter()
+        env.rollout_torch(tape[:K], out_slots)
+        sync_all()
+        f_elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
+        f_ms, f_steps = env.profile_read()
+        env.profile(False)
+        env.set_rollout_fused(1)
+        fused = {"steps_per_launch": args.fused, "value": whole_job_throughput(n, K, world, f_elapsed), "unit": "env-steps/s",
+                 "ms_per_step": 1e3 * f_elapsed / K, "device_us_per_step": 1e3 * f_ms / max(1, f_steps),
+                 "note": "same K steps through hlx_rollout with hlx_set_rollout_fused: state stays in registers for "
+                         "steps_per_launch steps, bit-identical results; not the headline (a policy in the loop needs one launch per step)"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(rc)
@@ -154,6 +175,7 @@ def main():
                          "kernel_us": kern_us, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "launches_timed": launches},
             "cpu_baseline": cpu,
+            "fused_rollout": fused,
         }
         print(json.dumps(line), flush=True)
     env.close()

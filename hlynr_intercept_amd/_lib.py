@@ -75,6 +75,7 @@ SYMBOLS = {
     "hlx_fill_noise": (C.c_int, [_P, _P, _P, i32, _P]),
     "hlx_get_state": (C.c_int, [_P, _P]),
     "hlx_set_state": (C.c_int, [_P, _P]),
+    "hlx_set_rollout_fused": (C.c_int, [_P, i32]),
     "hlx_profile": (C.c_int, [_P, i32]),
     "hlx_profile_read": (C.c_int, [_P, C.POINTER(f64), C.POINTER(i64)]),
     "hlx_num_envs": (i32, [_P]),

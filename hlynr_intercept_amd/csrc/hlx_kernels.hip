@@ -53,25 +53,50 @@ namespace {
 
 DEV double rr(double x, bool is64) { return is64 ? x : (double)(float)x; }
 
+// State / ring / observation stores are WRITE-THROUGH (`sc1`) buffer stores: nothing this launch stores is read
+// again before the next launch (whose acquire drops the L2 anyway), and with plain stores the ~21 MB a launch
+// writes would sit dirty in the XCD L2s until the end-of-kernel release writes it all back at once, after the
+// last wave has finished; written through, the bytes leave while the waves still compute and the release finds
+// the L2 clean (MI355X_MICROARCH.md, "stores of each flavour" / publish-large).
+#ifndef HLX_ST_AUX
+#define HLX_ST_AUX 16   // buffer-instruction cache bits: 16 = sc1 (write-through); 0 = plain (A/B builds)
+#endif
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+DEV void wt16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, float4 v) {
+    u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, HLX_ST_AUX);
+}
+DEV void wt16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, double2 v) {
+    u32x4 d = {(uint32_t)__double2loint(v.x), (uint32_t)__double2hiint(v.x), (uint32_t)__double2loint(v.y), (uint32_t)__double2hiint(v.y)};
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, HLX_ST_AUX);
+}
+
 // NOISE = parity-mode instantiation that can take its random draws from caller-supplied float64 buffers;
 // the production instantiation (NOISE = false) contains no trace of that path.
-template <uint32_t SPEC, int MODE /*0 = step, 1 = reset-only*/, bool NOISE>
+// PERSIST = the fused-rollout instantiation (hlx_rollout): the wave keeps its 64 environments' state in registers
+// over `T` consecutive steps -- state groups are read before the first and written after the last step; per
+// step only the action row and the delayed ring sample come in and observation/reward/flags/ring sample go out.
+// Same arithmetic, same Philox keys (clock t + k), hence bit-identical to T single-step launches.
+template <uint32_t SPEC, int MODE /*0 = step, 1 = reset-only*/, bool NOISE, bool PERSIST = false>
 __global__ __launch_bounds__(64) void hlx_env_kernel(
     // ---- 14 dwords preloaded into SGPRs by the dispatcher: everything needed to issue the state, action and
     //      ring loads and to run the Philox block without waiting for memory
-    float4* __restrict__ arena, const KParams* __restrict__ P, const float* __restrict__ actions,
-    const unsigned long long t, const unsigned long long seed, const long long env_offset, const int n,
+    float4* __restrict__ arena, const KParams* __restrict__ P, const float* __restrict__ actions0,
+    const unsigned long long t0, const unsigned long long seed, const long long env_offset, const int n,
     const uint32_t slots,   // bits 0-3 ground-ring read slot, 4-7 ground-ring write slot, 8-11 onboard-ring write slot,
                             // 12-15 ground-ring planes (delay+1, 0 = no ring), 16-19 onboard-ring planes (0 = no ring)
     // ---- ordinary kernarg tail (one scalar load, issued at entry, first needed when results are stored)
-    float* __restrict__ obs_out, float* __restrict__ reward_out, uint8_t* __restrict__ term_out,
-    uint8_t* __restrict__ trunc_out) {
+    float* __restrict__ obs_out0, float* __restrict__ reward_out0, uint8_t* __restrict__ term_out0,
+    uint8_t* __restrict__ trunc_out0,
+    // ---- fused rollout only: steps in this launch; output slot of the first step; output slots (step k of the
+    //      rollout writes slot k mod out_slots of the [out_slots][N][...] output arrays)
+    const int T, const int out_slot0, const int out_slots) {
     __shared__ __attribute__((aligned(16))) float tile[64 * HLX_OBS_DIM];
     const uint32_t FL = (SPEC & KF_DYNAMIC) ? P->hot.c.flags : SPEC;   // generic variant only: one scalar load
     const int lane = threadIdx.x;
     const int i = blockIdx.x * 64 + lane;
     const bool live = i < n;
-    const int g_rslot = (int)(slots & 15u), g_wslot = (int)((slots >> 4) & 15u), o_wslot = (int)((slots >> 8) & 15u);
+    int g_rslot = (int)(slots & 15u), g_wslot = (int)((slots >> 4) & 15u), o_wslot = (int)((slots >> 8) & 15u);
     const int g_planes = (int)((slots >> 12) & 15u), o_planes = (int)((slots >> 16) & 15u);   // preloaded: no *P needed
     float* row = tile + lane * HLX_OBS_DIM;
     bool done = false;
@@ -90,6 +115,11 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
     // group offsets are compile-time constants (no per-group 64-bit address arithmetic in SGPRs)
     float4* A = arena + (size_t)blockIdx.x * (N_GROUPS * 64) + lane;
     double2* AD = reinterpret_cast<double2*>(A);
+    // this wave's arena block as a buffer (stores only): lane offset in voffset, group offset in soffset
+    const __amdgpu_buffer_rsrc_t rsA =
+        __builtin_amdgcn_make_buffer_rsrc(arena + (size_t)blockIdx.x * (N_GROUPS * 64), 0, N_GROUPS * 64 * 16, 0x00020000);
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+#define STG(G, v) wt16(rsA, lane16, (uint32_t)(G) * 1024u, (v))
     // ------------------------------------------------------------------ issue every load up front
     // (state groups, action row, the delayed ground-ring sample whose slot depends only on the global
     // clock); the Philox draws below do not depend on them and run while the loads are in flight.
@@ -104,6 +134,37 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
     // cross-lane reads (v_readlane), so the lanes that hold them must have executed their loads even in a partial
     // tail block; padding lanes use the last live environment's addresses and their results are discarded.
     const int ic = live ? i : (n - 1);
+    float4 g_kfp = make_float4(0.f, 0.f, 0.f, 0.f);
+    double2 g_kf0 = make_double2(0., 0.), g_kf1 = g_kf0, g_kf2 = g_kf0;
+    // (Staging the block in LDS and letting every use be a broadcast ds_read was measured too: 190 fewer
+    // instructions, 33 fewer VGPRs, but +0.65 us/step at 65 536 envs -- the lone wave of a SIMD eats each
+    // ds_read's latency at the use site, while a v_readlane result is there after its issue cycles.)
+    KHot hot;
+    // hot parameter block -> uniform registers, one v_readlane per dword that is actually used
+#define BUILD_HOT()                                                                                                   \
+    do {                                                                                                              \
+        asm volatile("" : "+v"(hotw0), "+v"(hotw1));                                                                  \
+        uint32_t w_[sizeof(KHot) / 4];                                                                                \
+        _Pragma("unroll") for (int k_ = 0; k_ < (int)(sizeof(KHot) / 4); ++k_)                                        \
+            w_[k_] = __builtin_amdgcn_readlane(k_ < 64 ? hotw0 : hotw1, k_ & 63);                                     \
+        __builtin_memcpy(&hot, w_, sizeof(KHot));                                                                     \
+    } while (0)
+    // per-step cursors (advance only in the fused rollout)
+    unsigned long long t = t0;
+    const float* actions = actions0;
+    float* obs_out = obs_out0;
+    float* reward_out = reward_out0;
+    uint8_t* term_out = term_out0;
+    uint8_t* trunc_out = trunc_out0;
+    int oslot = out_slot0;
+    if (PERSIST) {   // the Kalman groups are loop-carried state too; constants once, before the loop
+        g_kfp = A[G_KFP * 64]; g_kf0 = AD[G_KF0 * 64]; g_kf1 = AD[G_KF1 * 64]; g_kf2 = AD[G_KF2 * 64];
+        BUILD_HOT();
+        if (obs_out0) obs_out = obs_out0 + (size_t)oslot * n * HLX_OBS_DIM;
+        reward_out = reward_out0 + (size_t)oslot * n; term_out = term_out0 + (size_t)oslot * n; trunc_out = trunc_out0 + (size_t)oslot * n;
+    }
+#pragma unroll 1
+    for (int kk = 0; kk < (PERSIST ? T : 1); ++kk) {
     {
         const size_t N = (size_t)n;
         // rings live right behind the (64-padded) arena in the same allocation: addresses need only preloaded values
@@ -121,8 +182,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 gr0 = *reinterpret_cast<const double2*>(R); gr1 = R[N]; gr2 = R[2 * N];
             }
         }
-        float4 g_kfp = A[G_KFP * 64];
-        double2 g_kf0 = AD[G_KF0 * 64], g_kf1 = AD[G_KF1 * 64], g_kf2 = AD[G_KF2 * 64];
+        if (!PERSIST) { g_kfp = A[G_KFP * 64]; g_kf0 = AD[G_KF0 * 64]; g_kf1 = AD[G_KF1 * 64]; g_kf2 = AD[G_KF2 * 64]; }
 
         STAMP(1);   // all loads issued
         const bool noise_buf = NOISE && P->hot.opt.step_noise != nullptr;    // parity instantiation only
@@ -176,15 +236,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
         // (the Kalman / ring registers are released further down, right before the observation section)
         // the output pointers of the kernarg tail have landed by now
         asm volatile("" ::"s"(obs_out), "s"(reward_out), "s"(term_out), "s"(trunc_out));
-        // hot parameter block -> uniform registers, one v_readlane per dword that is actually used
-        asm volatile("" : "+v"(hotw0), "+v"(hotw1));
-        KHot hot;
-        {
-            uint32_t w[sizeof(KHot) / 4];
-#pragma unroll
-            for (int k = 0; k < (int)(sizeof(KHot) / 4); ++k) w[k] = __builtin_amdgcn_readlane(k < 64 ? hotw0 : hotw1, k & 63);
-            __builtin_memcpy(&hot, w, sizeof(KHot));
-        }
+        if (!PERSIST) BUILD_HOT();
         const KCfg& c = hot.c;
         const KOpt* O = &hot.opt;
         if (!HAS(HLX_F_DOMAIN_RAND)) g_misc.z = c.peak;
@@ -847,26 +899,38 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
         if (MODE == 0 || done) {
             packed = (uint32_t)steps | ((uint32_t)worsening << 13) | ((uint32_t)crossed << 25) |
                      ((uint32_t)kf_init << 26) | ((uint32_t)kf_x64 << 27) | ((uint32_t)on_delay << 28);
-            A[G_IPOS * 64] = make_float4(ipos.x, ipos.y, ipos.z, fuel);
-            A[G_IVEL * 64] = make_float4(ivel.x, ivel.y, ivel.z, prev_distance);
-            A[G_QUAT * 64] = make_float4(q.w, q.x, q.y, q.z);
-            A[G_MPOS * 64] = make_float4(mpos.x, mpos.y, mpos.z, min_distance);
-            A[G_MVEL * 64] = make_float4(mvel.x, mvel.y, mvel.z, last_distance);
-            AD[G_W0 * 64] = make_double2(wind.x, wind.y);
-            if (HAS(HLX_F_THRUST_LAG)) A[G_THRUST * 64] = make_float4(thrust_act.x, thrust_act.y, thrust_act.z, 0.f);
-            A[G_W1 * 64] = make_float4(__int_as_float(__double2loint(wind.z)), __int_as_float(__double2hiint(wind.z)),
-                                      __uint_as_float(packed), ep_return);
-            AD[G_KF0 * 64] = make_double2(kxp.x, kxp.y);
-            AD[G_KF1 * 64] = make_double2(kxp.z, kxv.x);
-            AD[G_KF2 * 64] = make_double2(kxv.y, kxv.z);
-            A[G_KFP * 64] = make_float4(p_pp, p_pv, p_vp, p_vv);
-            if (HAS(HLX_F_DOMAIN_RAND)) A[G_MISC * 64] = make_float4(T0, dp.base_cd, dp.peak, 0.f);
-            if (c.o_delay > 0) oring[(size_t)o_wslot * N + i] = on_sample;
+            // fused rollout: the state stays in the registers it was loaded into; otherwise it goes back to the arena
+#define PUT4(G, reg, ...) do { if (PERSIST) reg = __VA_ARGS__; else STG(G, __VA_ARGS__); } while (0)
+#define PUT2(G, reg, ...) do { if (PERSIST) reg = __VA_ARGS__; else STG(G, __VA_ARGS__); } while (0)
+            PUT4(G_IPOS, g_ipos, make_float4(ipos.x, ipos.y, ipos.z, fuel));
+            PUT4(G_IVEL, g_ivel, make_float4(ivel.x, ivel.y, ivel.z, prev_distance));
+            PUT4(G_QUAT, g_quat, make_float4(q.w, q.x, q.y, q.z));
+            PUT4(G_MPOS, g_mpos, make_float4(mpos.x, mpos.y, mpos.z, min_distance));
+            PUT4(G_MVEL, g_mvel, make_float4(mvel.x, mvel.y, mvel.z, last_distance));
+            PUT2(G_W0, g_w0, make_double2(wind.x, wind.y));
+            if (HAS(HLX_F_THRUST_LAG)) PUT4(G_THRUST, g_thr, make_float4(thrust_act.x, thrust_act.y, thrust_act.z, 0.f));
+            PUT4(G_W1, g_w1, make_float4(__int_as_float(__double2loint(wind.z)), __int_as_float(__double2hiint(wind.z)),
+                                         __uint_as_float(packed), ep_return));
+            PUT2(G_KF0, g_kf0, make_double2(kxp.x, kxp.y));
+            PUT2(G_KF1, g_kf1, make_double2(kxp.z, kxv.x));
+            PUT2(G_KF2, g_kf2, make_double2(kxv.y, kxv.z));
+            PUT4(G_KFP, g_kfp, make_float4(p_pp, p_pv, p_vp, p_vv));
+            if (HAS(HLX_F_DOMAIN_RAND)) PUT4(G_MISC, g_misc, make_float4(T0, dp.base_cd, dp.peak, 0.f));
+#undef PUT4
+#undef PUT2
+            const uint32_t blk_bytes = (uint32_t)min(64, n - (int)blockIdx.x * 64) * 16u;   // partial tail block: clip
+            if (c.o_delay > 0) {
+                const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
+                    oring + (size_t)o_wslot * N + (size_t)blockIdx.x * 64, 0, blk_bytes, 0x00020000);
+                wt16(rsO, lane16, 0u, on_sample);
+            }
             if (HAS(HLX_F_GROUND) && c.g_delay > 0) {
-                float4* R = gring + ((size_t)g_wslot * GROUND_RING_WORDS16) * N + i;
-                *reinterpret_cast<double2*>(R) = make_double2(g_sp.x, g_sp.y);
-                R[N] = make_float4(__int_as_float(__double2loint(g_sp.z)), __int_as_float(__double2hiint(g_sp.z)), g_sq, g_sflag);
-                R[2 * N] = g_s2;
+                // the slot's three planes are N words apart: one descriptor per plane keeps every offset 32-bit at any N
+                float4* R = gring + ((size_t)g_wslot * GROUND_RING_WORDS16) * N + (size_t)blockIdx.x * 64;
+                wt16(__builtin_amdgcn_make_buffer_rsrc(R, 0, blk_bytes, 0x00020000), lane16, 0u, make_double2(g_sp.x, g_sp.y));
+                wt16(__builtin_amdgcn_make_buffer_rsrc(R + N, 0, blk_bytes, 0x00020000), lane16, 0u,
+                     make_float4(__int_as_float(__double2loint(g_sp.z)), __int_as_float(__double2hiint(g_sp.z)), g_sq, g_sflag));
+                wt16(__builtin_amdgcn_make_buffer_rsrc(R + 2 * N, 0, blk_bytes, 0x00020000), lane16, 0u, g_s2);
             }
         }
         if (MODE == 0) {
@@ -879,7 +943,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
 
     STAMP(14);      // state / ring / scalar outputs stored
     // -------------------------------------------------------------------------- done-mask compaction
-    if (MODE == 0 && done_idx_out) {
+    if (MODE == 0 && !PERSIST && done_idx_out) {
         const unsigned long long m = __ballot(live && done);
         if (m) {
             int base = 0;
@@ -898,14 +962,14 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
         if (MODE == 0) {
             if (rows == 64) {
                 const float4* src4 = reinterpret_cast<const float4*>(tile);
-                float4* dst4 = reinterpret_cast<float4*>(dst);
+                const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 64 * HLX_OBS_DIM * 4, 0x00020000);
                 float4 v[7];   // all LDS reads first (one wait), then the stores
 #pragma unroll
                 for (int r = 0; r < 6; ++r) v[r] = src4[lane + 64 * r];
                 v[6] = (lane < 64 * HLX_OBS_DIM / 4 - 384) ? src4[lane + 384] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int r = 0; r < 6; ++r) dst4[lane + 64 * r] = v[r];
-                if (lane < 64 * HLX_OBS_DIM / 4 - 384) dst4[lane + 384] = v[6];
+                for (int r = 0; r < 6; ++r) wt16(rsT, lane16, 1024u * r, v[r]);
+                if (lane < 64 * HLX_OBS_DIM / 4 - 384) wt16(rsT, lane16, 6144u, v[6]);
             } else {
                 for (int j = lane; j < rows * HLX_OBS_DIM; j += 64) dst[j] = tile[j];
             }
@@ -914,6 +978,27 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
         }
     }
     STAMP(15);      // observation tile stored
+    if (PERSIST) {   // next step of the fused rollout: clock, ring slots (mod their capacities), I/O cursors
+        t += 1ull;
+        g_rslot = (g_rslot + 1 >= g_planes) ? 0 : g_rslot + 1;
+        g_wslot = (g_wslot + 1 >= g_planes) ? 0 : g_wslot + 1;
+        o_wslot = (o_wslot + 1 >= o_planes) ? 0 : o_wslot + 1;
+        actions += (size_t)n * HLX_ACT_DIM;
+        oslot = (oslot + 1 >= out_slots) ? 0 : oslot + 1;
+        if (obs_out0) obs_out = obs_out0 + (size_t)oslot * n * HLX_OBS_DIM;
+        reward_out = reward_out0 + (size_t)oslot * n; term_out = term_out0 + (size_t)oslot * n; trunc_out = trunc_out0 + (size_t)oslot * n;
+        done = false;
+        __syncthreads();   // the tile is rewritten by the next step
+    }
+    }   // step loop
+#undef BUILD_HOT
+    if (PERSIST && live) {   // state back to the arena, once
+        STG(G_IPOS, g_ipos); STG(G_IVEL, g_ivel); STG(G_QUAT, g_quat); STG(G_MPOS, g_mpos); STG(G_MVEL, g_mvel);
+        STG(G_W0, g_w0); STG(G_W1, g_w1);
+        if (HAS(HLX_F_THRUST_LAG)) STG(G_THRUST, g_thr);
+        STG(G_KF0, g_kf0); STG(G_KF1, g_kf1); STG(G_KF2, g_kf2); STG(G_KFP, g_kfp);
+        if (HAS(HLX_F_DOMAIN_RAND)) STG(G_MISC, g_misc);
+    }
 }
 
 }  // namespace

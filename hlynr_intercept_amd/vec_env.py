@@ -354,6 +354,10 @@ class HlynrVecEnv:
         self._torch.cuda.synchronize(self.device)
         _lib.check(self._lib.hlx_set_state(self._h, C.addressof(arr)))
 
+    def set_rollout_fused(self, steps_per_launch: int):
+        """1 = one launch per step (default); k > 1 = rollout_torch keeps the state on-chip for k steps per launch."""
+        _lib.check(self._lib.hlx_set_rollout_fused(self._h, int(steps_per_launch)))
+
     def profile(self, enable: bool):
         _lib.check(self._lib.hlx_profile(self._h, int(enable)))
 

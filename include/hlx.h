@@ -156,11 +156,18 @@ int hlx_step(hlx_env *env, const float *actions, float *obs, float *reward, uint
              uint8_t *truncated, float *terminal_obs, int32_t *done_idx, int32_t *n_done,
              const hlx_info_soa *info, void *stream);
 
-/* T consecutive steps from a pre-supplied action tape [T][N][6], one launch per step issued from C
- * (benchmark / open-loop evaluation path).  Outputs of step t go to slot (t % out_slots) of
- * obs [out_slots][N][26], reward/terminated/truncated [out_slots][N] (out_slots >= 1). */
+/* T consecutive steps from a pre-supplied action tape [T][N][6], launches issued from C
+ * (benchmark / open-loop evaluation path; the reference's equivalent is a `for t: env.step(tape[t])` loop).
+ * Outputs of step t go to slot (t % out_slots) of obs [out_slots][N][26],
+ * reward/terminated/truncated [out_slots][N] (out_slots >= 1). */
 int hlx_rollout(hlx_env *env, const float *actions, int32_t T, int32_t out_slots, float *obs, float *reward,
                 uint8_t *terminated, uint8_t *truncated, void *stream);
+/* How hlx_rollout issues its steps: 1 (default) = one kernel launch per step, exactly what hlx_step does;
+ * k > 1 = fused rollout, up to k steps per launch with the environments' state held in registers between
+ * steps (state groups touch HBM once per launch; per step only actions/ring samples in and
+ * observation/reward/flags/ring samples out).  Results are bit-identical either way (same Philox keys).
+ * Ignored (falls back to 1) while hlx_set_noise buffers are installed. */
+int hlx_set_rollout_fused(hlx_env *env, int32_t steps_per_launch);
 
 /* environment.py:269 set_training_step_count(): O(1) host-side; evaluates the curriculum
  * schedules (environment.py:223-234, :274-351) and the result rides along as kernel arguments. */

@@ -112,3 +112,39 @@ def test_invariants_at_full_size():
     steps = np.array([st[i].steps for i in range(0, 65536, 97)])
     assert steps.max() < 150 and n_done >= 2 * 65536                        # every env truncated at least twice
     env.close()
+
+
+@pytest.mark.parametrize("physics,n", [("base", 1000), ("v2dr", 333), ("v2", 64)])
+def test_fused_rollout_is_bit_identical_to_single_step_launches(physics, n):
+    """hlx_set_rollout_fused(k): k steps per launch with the state held in registers must reproduce the
+    one-launch-per-step rollout bit for bit (same Philox keys, same arithmetic), including auto-resets
+    (max_steps 40 forces several per env), a chunk size that does not divide T, a partial tail block and
+    the rotation of the output slots."""
+    import torch
+    T, slots = 131, 7
+    over = {"max_steps": 40}
+    ref, fus = _env(n, physics, over, seed=5), _env(n, physics, over, seed=5)
+    g = torch.Generator(device=ref.device).manual_seed(1)
+    tape = torch.rand((T, n, 6), generator=g, device=ref.device) * 2 - 1
+    o0, o1 = ref.reset_torch().clone(), fus.reset_torch().clone()
+    assert torch.equal(o0, o1)
+    fus.set_rollout_fused(32)
+    # first half in one call, second half in another: the clock and the ring slots carry across launches
+    outs = []
+    for env in (ref, fus):
+        acc = []
+        for lo, hi in ((0, 70), (70, T)):
+            o, r, te, tr = env.rollout_torch(tape[lo:hi], slots)
+            acc.append([x.clone() for x in (o, r, te, tr)])
+        outs.append(acc)
+    for a, b in zip(outs[0], outs[1]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    sa, sb = ref.get_state(), fus.get_state()
+    assert bytes(sa) == bytes(sb)                                        # full logical state, rings included
+    assert max(sa[i].steps for i in range(n)) < 40                       # episodes did end (and restart) inside the window
+    # and both keep stepping identically through the ordinary step entry point
+    a = tape[0]
+    ra, rb = ref.step_torch(a), fus.step_torch(a)
+    assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1])
+    ref.close(); fus.close()
