@@ -61,7 +61,13 @@ class HlxEnvState(C.Structure):
     ]
 
 
-# every symbol include/hlx.h declares: (restype, argtypes)
+class HlxObsConfig(C.Structure):   # include/hlx_obs.h hlx_obs_config
+    _fields_ = [("n_envs", i32), ("obs_dim", i32), ("n_stack", i32), ("device", i32), ("norm_obs", i32),
+                ("norm_reward", i32), ("training", i32), ("pad0", i32), ("clip_obs", f64), ("clip_reward", f64),
+                ("gamma", f64), ("epsilon", f64)]
+
+
+# every symbol include/hlx.h and include/hlx_obs.h declare: (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
     "hlx_create": (C.c_int, [C.POINTER(HlxConfig), i32, i32, u64, i64, C.POINTER(_P)]),
@@ -85,6 +91,17 @@ SYMBOLS = {
     "hlx_sizeof_env_state": (i32, []),
     "hlx_last_error": (C.c_char_p, []),
     "hlx_version": (C.c_char_p, []),
+    # include/hlx_obs.h
+    "hlx_obs_create": (C.c_int, [C.POINTER(HlxObsConfig), C.POINTER(_P)]),
+    "hlx_obs_destroy": (C.c_int, [_P]),
+    "hlx_obs_next_slot": (_P, [_P]),
+    "hlx_obs_push_reset": (C.c_int, [_P, _P, _P]),
+    "hlx_obs_push": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "hlx_obs_emit": (C.c_int, [_P, i32, _P, _P]),
+    "hlx_obs_set_mode": (C.c_int, [_P, i32, i32, i32]),
+    "hlx_obs_get_stats": (C.c_int, [_P, _P, _P, _P]),
+    "hlx_obs_set_stats": (C.c_int, [_P, _P, _P, _P]),
+    "hlx_obs_feature_dim": (i32, [_P]),
 }
 
 _lib = None

@@ -1005,3 +1005,5 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
 
 // host side of the C ABI
 #include "hlx_host.inc"
+// on-device VecFrameStack + VecNormalize behind the step (include/hlx_obs.h)
+#include "hlx_obs.inc"

@@ -172,17 +172,19 @@ class HlynrVecEnv:
         return self._lib.hlx_kernel_variant(self._h).decode()
 
     # ------------------------------------------------------------------ torch / gymnasium-vector style API
-    def reset_torch(self, mask=None):
-        """Reset all envs (or those where `mask` is non-zero); returns the device obs tensor [N, 26]."""
+    def reset_torch(self, mask=None, obs_ptr: Optional[int] = None):
+        """Reset all envs (or those where `mask` is non-zero); returns the device obs tensor [N, 26].
+        `obs_ptr`: raw device address to write the observations to instead (the frame ring of wrappers.py)."""
         mptr = None
         if mask is not None:
             mask = mask.to(device=self.device, dtype=self._torch.uint8).contiguous()
             mptr = mask.data_ptr()
-        _lib.check(self._lib.hlx_reset(self._h, mptr, self.obs.data_ptr(), self._stream()))
+        _lib.check(self._lib.hlx_reset(self._h, mptr, obs_ptr if obs_ptr is not None else self.obs.data_ptr(), self._stream()))
         return self.obs
 
-    def step_torch(self, actions, want_done_list: bool = False):
+    def step_torch(self, actions, want_done_list: bool = False, obs_ptr: Optional[int] = None):
         """One vec step on device tensors.  `actions`: float32 [N, 6] on this device.
+        `obs_ptr`: raw device address the observations go to instead of `self.obs` (wrappers.py's frame ring).
 
         Returns (obs, reward, terminated, truncated, info) - all torch tensors living on the GPU; they are
         overwritten by the next call (clone what must survive)."""
@@ -193,7 +195,8 @@ class HlynrVecEnv:
             raise ValueError(f"actions must have shape ({self.num_envs}, {_lib.ACT_DIM}), got {tuple(actions.shape)}")
         di = self.done_idx.data_ptr() if want_done_list else None
         nd = self.n_done.data_ptr() if want_done_list else None
-        _lib.check(self._lib.hlx_step(self._h, actions.data_ptr(), self.obs.data_ptr(), self.reward.data_ptr(),
+        _lib.check(self._lib.hlx_step(self._h, actions.data_ptr(), obs_ptr if obs_ptr is not None else self.obs.data_ptr(),
+                                      self.reward.data_ptr(),
                                       self.terminated.data_ptr(), self.truncated.data_ptr(),
                                       self.terminal_obs.data_ptr(), di, nd, C.byref(self._info_soa), self._stream()))
         info = dict(self.info)
@@ -238,6 +241,10 @@ class HlynrVecEnv:
             raise RuntimeError("step_wait() called without step_async()")
         obs, rew, term, trunc, info = self._pending
         self._pending = None
+        return self._materialise(obs, rew, term, trunc, info, self.terminal_obs)
+
+    def _materialise(self, obs, rew, term, trunc, info, terminal):
+        """Device step results -> the numpy (obs, rewards, dones, infos) tuple SB3 expects (one D2H copy each)."""
         obs_h = obs.cpu().numpy()
         rew_h = rew.cpu().numpy()
         term_h = term.cpu().numpy().astype(bool)
@@ -251,7 +258,7 @@ class HlynrVecEnv:
         if n_done:
             idx = self.done_idx[:n_done].to(self._torch.int64)
             idx_h = idx.cpu().numpy()
-            host["terminal_obs"] = self.terminal_obs.index_select(0, idx).cpu().numpy()
+            host["terminal_obs"] = terminal.index_select(0, idx).cpu().numpy()
             host["ep_return"] = self.info["episode_return"].index_select(0, idx).cpu().numpy()
             host["ep_length"] = self.info["episode_length"].index_select(0, idx).cpu().numpy()
             done_rows = {int(e): r for r, e in enumerate(idx_h)}

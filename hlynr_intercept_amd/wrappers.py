@@ -1,0 +1,263 @@
+"""On-device `VecFrameStack` and `VecNormalize` for `HlynrVecEnv`.
+
+Drop-in for the two Stable-Baselines3 wrappers the reference's trainers apply
+(rl_system/scripts/train_flat_ppo.py:384-399, train_hrl_pretrain.py:367-387):
+
+    from hlynr_intercept_amd.wrappers import VecFrameStack, VecNormalize
+    envs = VecFrameStack(envs, n_stack=frame_stack)
+    envs = VecNormalize(envs, norm_obs=True, norm_reward=False, clip_obs=10.0, clip_reward=10.0, gamma=gamma)
+
+Same constructor arguments, attributes (`training`, `norm_reward`, `obs_rms`, `ret_rms`, `venv`, ...) and step
+semantics as SB3 2.x (restated in oracle/vec_wrappers.py; C ABI and algorithm notes in include/hlx_obs.h).  The work
+happens in libhlx.so: the step kernel writes each new observation straight into the pipeline's frame ring, and one
+`hlx_obs_push` reduces the batch moments, merges the running statistics and emits the stacked, normalised
+[N, n_stack*26] float32 batch.  `VecNormalize(VecFrameStack(env))` collapses into ONE pipeline (stack + normalise in
+the same kernels); there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import pickle
+from typing import Any, Optional
+
+import numpy as np
+
+from . import _lib
+from .vec_env import HlynrVecEnv, _box
+
+
+class _RmsView:
+    """`venv.obs_rms` / `venv.ret_rms`: SB3 RunningMeanStd attributes (`mean`, `var`, `count`), read from the device."""
+
+    def __init__(self, owner, which):
+        self._o, self._w = owner, which
+
+    def _get(self):
+        mean, var, sc = self._o._get_stats()
+        return (mean, var, sc[0]) if self._w == "obs" else (np.float64(sc[1]), np.float64(sc[2]), sc[3])
+
+    mean = property(lambda s: s._get()[0])
+    var = property(lambda s: s._get()[1])
+    count = property(lambda s: s._get()[2])
+
+
+class _DeviceObsWrapper:
+    """Shared machinery: one `hlx_obs` pipeline behind one `HlynrVecEnv`."""
+
+    def __init__(self, venv, n_stack, norm_obs, norm_reward, training, clip_obs, clip_reward, gamma, epsilon):
+        base = venv
+        while isinstance(base, _DeviceObsWrapper):
+            base = base.venv
+        if not isinstance(base, HlynrVecEnv):
+            raise TypeError("the on-device wrappers wrap a HlynrVecEnv (or one another)")
+        self.venv, self._base = venv, base
+        self._torch, self._lib = base._torch, base._lib
+        self.num_envs, self.device, self.action_space = base.num_envs, base.device, base.action_space
+        self.n_stack = int(n_stack)
+        self._cfg = _lib.HlxObsConfig(n_envs=base.num_envs, obs_dim=_lib.OBS_DIM, n_stack=self.n_stack,
+                                      device=base.device_index, norm_obs=int(norm_obs), norm_reward=int(norm_reward),
+                                      training=int(training), clip_obs=float(clip_obs), clip_reward=float(clip_reward),
+                                      gamma=float(gamma), epsilon=float(epsilon))
+        self._p = C.c_void_p()
+        _lib.check(self._lib.hlx_obs_create(C.byref(self._cfg), C.byref(self._p)))
+        self.feature_dim = int(self._lib.hlx_obs_feature_dim(self._p))
+        t, n, dev = self._torch, self.num_envs, self.device
+        self.stacked = t.zeros((n, self.feature_dim), dtype=t.float32, device=dev)
+        self.terminal_stacked = t.zeros((n, self.feature_dim), dtype=t.float32, device=dev)
+        self.reward_out = t.zeros(n, dtype=t.float32, device=dev)
+        self._orig = None
+        self._pending = None
+        self._closed = False
+
+    # ------------------------------------------------------------------ plumbing
+    def _absorb(self, inner):
+        """`VecNormalize(VecFrameStack(env))`: this pipeline does both jobs; the inner wrapper's handle is released."""
+        inner._release()
+
+    def _release(self):
+        if not self._closed and self._p:
+            self._torch.cuda.synchronize(self.device)
+            self._lib.hlx_obs_destroy(self._p)
+            self._closed = True
+
+    def close(self):
+        self._release()
+        self._base.close()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def __getattr__(self, name):          # env_method, get_attr, set_training_step_count, curriculum, ... pass through
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self._base, name)
+
+    def _mode(self):
+        _lib.check(self._lib.hlx_obs_set_mode(self._p, int(self._training), int(self._norm_obs), int(self._norm_reward)))
+
+    def _get_stats(self):
+        mean, var = np.zeros(self.feature_dim), np.zeros(self.feature_dim)
+        sc = (C.c_double * 4)()
+        _lib.check(self._lib.hlx_obs_get_stats(self._p, mean.ctypes.data, var.ctypes.data, C.addressof(sc)))
+        return mean, var, [float(x) for x in sc]
+
+    def _set_stats(self, mean, var, scalars):
+        mean, var = np.ascontiguousarray(mean, np.float64), np.ascontiguousarray(var, np.float64)
+        if mean.shape != (self.feature_dim,) or var.shape != (self.feature_dim,):
+            raise ValueError(f"statistics must have shape ({self.feature_dim},)")
+        sc = (C.c_double * 4)(*[float(x) for x in scalars])
+        _lib.check(self._lib.hlx_obs_set_stats(self._p, mean.ctypes.data, var.ctypes.data, C.addressof(sc)))
+
+    # ------------------------------------------------------------------ device API (torch tensors, no host round trip)
+    def reset_torch(self):
+        b = self._base
+        b.reset_torch(obs_ptr=self._lib.hlx_obs_next_slot(self._p))
+        _lib.check(self._lib.hlx_obs_push_reset(self._p, self.stacked.data_ptr(), b._stream()))
+        return self.stacked
+
+    def step_torch(self, actions, want_done_list: bool = False):
+        """(stacked obs [N, n_stack*26], reward, terminated, truncated, info); info['terminal_observation'] holds the
+        stacked (and normalised) terminal observation in the rows of finished environments."""
+        b = self._base
+        _, rew, term, trunc, info = b.step_torch(actions, want_done_list, obs_ptr=self._lib.hlx_obs_next_slot(self._p))
+        _lib.check(self._lib.hlx_obs_push(self._p, term.data_ptr(), trunc.data_ptr(), b.terminal_obs.data_ptr(), rew.data_ptr(),
+                                          self.stacked.data_ptr(), self.terminal_stacked.data_ptr(), self.reward_out.data_ptr(),
+                                          b._stream()))
+        info = dict(info)
+        info["terminal_observation"] = self.terminal_stacked
+        info["original_reward"] = rew
+        return self.stacked, self.reward_out, term, trunc, info
+
+    def get_original_obs_torch(self):
+        """Un-normalised stacked observations of the last step (VecNormalize.get_original_obs)."""
+        if self._orig is None:
+            self._orig = self._torch.zeros_like(self.stacked)
+        _lib.check(self._lib.hlx_obs_emit(self._p, 0, self._orig.data_ptr(), self._base._stream()))
+        return self._orig
+
+    # ------------------------------------------------------------------ SB3 VecEnv API (numpy at the boundary)
+    def reset(self):
+        import time
+        self._base._t_start = time.time()
+        return self.reset_torch().cpu().numpy()
+
+    def step_async(self, actions):
+        b = self._base
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        if a.shape != (self.num_envs, _lib.ACT_DIM):
+            raise ValueError(f"actions must have shape ({self.num_envs}, {_lib.ACT_DIM}), got {a.shape}")
+        b._actions_dev.copy_(self._torch.from_numpy(a))
+        self._pending = self.step_torch(b._actions_dev, want_done_list=True)
+
+    def step_wait(self):
+        if self._pending is None:
+            raise RuntimeError("step_wait() called without step_async()")
+        obs, rew, term, trunc, info = self._pending
+        self._pending = None
+        return self._base._materialise(obs, rew, term, trunc, info, self.terminal_stacked)
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+
+class VecFrameStack(_DeviceObsWrapper):
+    """SB3 `VecFrameStack(venv, n_stack)` for the 1-D observation: newest frame last, zero-filled after a reset."""
+
+    def __init__(self, venv, n_stack: int, channels_order: Optional[str] = None):
+        if channels_order not in (None, "last"):
+            raise ValueError("1-D observations stack along the last axis")
+        super().__init__(venv, n_stack, norm_obs=False, norm_reward=False, training=False, clip_obs=10.0, clip_reward=10.0,
+                         gamma=0.99, epsilon=1e-8)
+        self._training, self._norm_obs, self._norm_reward = False, False, False
+        self.observation_space = _box(-2.0, 1.0, (self.feature_dim,))
+
+
+class VecNormalize(_DeviceObsWrapper):
+    """SB3 `VecNormalize`: running mean/variance normalisation of observations (and optionally rewards)."""
+
+    def __init__(self, venv, training: bool = True, norm_obs: bool = True, norm_reward: bool = True, clip_obs: float = 10.0,
+                 clip_reward: float = 10.0, gamma: float = 0.99, epsilon: float = 1e-8, norm_obs_keys: Any = None):
+        if norm_obs_keys is not None:
+            raise ValueError("norm_obs_keys applies to Dict observation spaces; the intercept observation is a Box")
+        n_stack = venv.n_stack if isinstance(venv, VecFrameStack) else 1
+        super().__init__(venv, n_stack, norm_obs, norm_reward, training, clip_obs, clip_reward, gamma, epsilon)
+        if isinstance(venv, VecFrameStack):
+            self._absorb(venv)
+        self._training, self._norm_obs, self._norm_reward = bool(training), bool(norm_obs), bool(norm_reward)
+        self.clip_obs, self.clip_reward, self.gamma, self.epsilon = float(clip_obs), float(clip_reward), float(gamma), float(epsilon)
+        self.observation_space = _box(-2.0, 1.0, (self.feature_dim,))   # SB3 keeps the wrapped space
+        self.obs_rms, self.ret_rms = _RmsView(self, "obs"), _RmsView(self, "ret")
+
+    training = property(lambda s: s._training)
+    norm_obs = property(lambda s: s._norm_obs)
+    norm_reward = property(lambda s: s._norm_reward)
+
+    @training.setter
+    def training(self, v):
+        self._training = bool(v)
+        self._mode()
+
+    @norm_obs.setter
+    def norm_obs(self, v):
+        self._norm_obs = bool(v)
+        self._mode()
+
+    @norm_reward.setter
+    def norm_reward(self, v):
+        self._norm_reward = bool(v)
+        self._mode()
+
+    def normalize_obs(self, obs):
+        """clip((obs - mean) / sqrt(var + eps)) with the current statistics; numpy in, float32 numpy out."""
+        if not self._norm_obs:
+            return obs
+        mean, var, _ = self._get_stats()
+        return np.clip((np.asarray(obs) - mean) / np.sqrt(var + self.epsilon), -self.clip_obs, self.clip_obs).astype(np.float32)
+
+    def normalize_reward(self, reward):
+        if not self._norm_reward:
+            return reward
+        _, _, sc = self._get_stats()
+        return np.clip(np.asarray(reward) / np.sqrt(sc[2] + self.epsilon), -self.clip_reward, self.clip_reward).astype(np.float32)
+
+    def get_original_obs(self):
+        return self.get_original_obs_torch().cpu().numpy()
+
+    def get_original_reward(self):
+        return self._base.reward.cpu().numpy()
+
+    # ------------------------------------------------------------------ persistence (train_flat_ppo.py:528-531, inference.py:450-477)
+    def state_dict(self):
+        mean, var, sc = self._get_stats()
+        return {"format": "hlynr-vecnormalize-v1", "obs_mean": mean, "obs_var": var, "obs_count": sc[0], "ret_mean": sc[1],
+                "ret_var": sc[2], "ret_count": sc[3], "clip_obs": self.clip_obs, "clip_reward": self.clip_reward,
+                "gamma": self.gamma, "epsilon": self.epsilon, "norm_obs": self._norm_obs, "norm_reward": self._norm_reward,
+                "training": self._training, "n_stack": self.n_stack}
+
+    def save(self, path: str) -> None:
+        """Pickle of the running statistics and settings (a plain dict; `load` also accepts an SB3 VecNormalize pickle)."""
+        with open(path, "wb") as f:
+            pickle.dump(self.state_dict(), f)
+
+    @staticmethod
+    def load(path: str, venv) -> "VecNormalize":
+        """Counterpart of SB3's `VecNormalize.load(load_path, venv)`.  Reads this module's own format, or -- where
+        stable-baselines3 is importable -- a `vec_normalize.pkl` written by the reference's trainers."""
+        with open(path, "rb") as f:
+            obj = pickle.load(f)
+        if isinstance(obj, dict) and obj.get("format") == "hlynr-vecnormalize-v1":
+            d = obj
+        else:   # an SB3 VecNormalize instance: same attribute names
+            d = {"obs_mean": obj.obs_rms.mean, "obs_var": obj.obs_rms.var, "obs_count": obj.obs_rms.count,
+                 "ret_mean": obj.ret_rms.mean, "ret_var": obj.ret_rms.var, "ret_count": obj.ret_rms.count,
+                 "clip_obs": obj.clip_obs, "clip_reward": obj.clip_reward, "gamma": obj.gamma, "epsilon": obj.epsilon,
+                 "norm_obs": obj.norm_obs, "norm_reward": obj.norm_reward, "training": obj.training}
+        out = VecNormalize(venv, training=d["training"], norm_obs=d["norm_obs"], norm_reward=d["norm_reward"],
+                           clip_obs=d["clip_obs"], clip_reward=d["clip_reward"], gamma=d["gamma"], epsilon=d["epsilon"])
+        out._set_stats(np.asarray(d["obs_mean"], np.float64).reshape(-1), np.asarray(d["obs_var"], np.float64).reshape(-1),
+                       [d["obs_count"], float(d["ret_mean"]), float(d["ret_var"]), d["ret_count"]])
+        return out

@@ -1,5 +1,5 @@
 """The C ABI library loads (ROCm runtime present, no GPU needed) and exports every symbol that
-include/hlx.h declares; argument validation works without touching a device."""
+include/hlx.h and include/hlx_obs.h declare; argument validation works without touching a device."""
 import ctypes as C
 import os
 import re
@@ -14,9 +14,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "hlx.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(hlx_[a-z_0-9]+)\s*\(", txt)))
+    out = set()
+    for header in ("hlx.h", "hlx_obs.h"):
+        txt = open(os.path.join(ROOT, "include", header)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        out |= set(re.findall(r"\b(hlx_[a-z_0-9]+)\s*\(", txt))
+    return sorted(out)
 
 
 def test_header_and_binding_agree():
@@ -44,6 +47,15 @@ def test_argument_validation_without_a_device():
     assert lib.hlx_create(C.byref(cfg), 16, 0, 0, 0, C.byref(h)) == -1 and b"max_steps" in lib.hlx_last_error()
     assert lib.hlx_step(None, None, None, None, None, None, None, None, None, None, None) == -1
     assert lib.hlx_destroy(None) == 0
+    # observation pipeline (include/hlx_obs.h)
+    p = C.c_void_p()
+    oc = _lib.HlxObsConfig(n_envs=16, obs_dim=26, n_stack=99, device=0, norm_obs=1, norm_reward=0, training=1,
+                           clip_obs=10.0, clip_reward=10.0, gamma=0.99, epsilon=1e-8)
+    assert lib.hlx_obs_create(C.byref(oc), C.byref(p)) == -1 and b"n_stack" in lib.hlx_last_error()
+    assert lib.hlx_obs_create(None, C.byref(p)) == -1
+    assert lib.hlx_obs_push(None, None, None, None, None, None, None, None, None) == -1
+    assert lib.hlx_obs_destroy(None) == 0 and lib.hlx_obs_feature_dim(None) == 0
+    assert C.sizeof(_lib.HlxObsConfig) == 64
 
 
 def test_config_struct_carries_the_flags():

@@ -1,0 +1,147 @@
+"""On-device VecFrameStack + VecNormalize (include/hlx_obs.h, hlynr_intercept_amd/wrappers.py) against the numpy
+restatement of the SB3 wrappers (oracle/vec_wrappers.py), fed with the raw step outputs of an identically seeded
+un-wrapped environment.  Tolerances: the raw stacks are bit-exact; normalised values agree to 1e-5 relative
+(float64 statistics on both sides; the GPU multiplies by a float64 reciprocal where numpy divides)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+RTOL, ATOL = 1e-5, 2e-6
+
+
+def _make(n, seed=9, max_steps=23):
+    from hlynr_intercept_amd.scenarios import scenario_config
+    from hlynr_intercept_amd.vec_env import HlynrVecEnv
+    return HlynrVecEnv(scenario_config("medium", "base", {"max_steps": max_steps}), num_envs=n, seed=seed)
+
+
+def _raw_trace(n, T, seed=9):
+    """Raw (obs0, [obs, reward, done, terminal_obs] per step, actions) of the un-wrapped environment."""
+    import torch
+    env = _make(n, seed)
+    g = torch.Generator(device=env.device).manual_seed(4)
+    acts = torch.rand((T, n, 6), generator=g, device=env.device) * 2 - 1
+    obs0 = env.reset_torch().cpu().numpy().copy()
+    steps = []
+    for t in range(T):
+        o, r, te, tr, info = env.step_torch(acts[t])
+        steps.append((o.cpu().numpy().copy(), r.cpu().numpy().copy(), ((te | tr) != 0).cpu().numpy(),
+                      info["terminal_observation"].cpu().numpy().copy()))
+    env.close()
+    return obs0, steps, acts
+
+
+@pytest.mark.parametrize("n,n_stack,norm_reward", [(257, 4, False), (64, 1, True), (1000, 3, True)])
+def test_stack_and_normalize_match_the_sb3_restatement(n, n_stack, norm_reward):
+    from hlynr_intercept_amd.wrappers import VecFrameStack, VecNormalize
+    from oracle.vec_wrappers import FrameStack, Normalize
+    T = 70
+    obs0, steps, acts = _raw_trace(n, T)
+    env = _make(n)
+    wrapped = VecNormalize(VecFrameStack(env, n_stack=n_stack) if n_stack > 1 else env, norm_obs=True,
+                           norm_reward=norm_reward, clip_obs=10.0, clip_reward=10.0, gamma=0.99)
+    assert wrapped.observation_space.shape == (26 * n_stack,)
+    fs, nz = FrameStack(n, 26, n_stack), Normalize(n, 26 * n_stack, norm_reward=norm_reward)
+    nz32 = Normalize(n, 26 * n_stack, norm_reward=norm_reward, batch_f32=True)   # SB3's float32 batch moments
+    fs32 = FrameStack(n, 26, n_stack)
+    got = wrapped.reset_torch().cpu().numpy()
+    want = nz.reset(fs.reset(obs0))
+    nz32.reset(fs32.reset(obs0))
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
+    n_done, worst32 = 0, 0.0
+    for t in range(T):
+        o, r, te, tr, info = wrapped.step_torch(acts[t])
+        raw_o, raw_r, done, raw_term = steps[t]
+        stacked, term_stacked = fs.step(raw_o, done, raw_term)
+        want_o, want_r, want_t = nz.step(stacked, raw_r, done, term_stacked)
+        s32, t32 = fs32.step(raw_o, done, raw_term)
+        o32, _, _ = nz32.step(s32, raw_r, done, t32)
+        got_o = o.cpu().numpy()
+        assert np.array_equal(((te | tr) != 0).cpu().numpy(), done)
+        np.testing.assert_allclose(got_o, want_o, rtol=RTOL, atol=ATOL, err_msg=f"step {t}")
+        np.testing.assert_allclose(r.cpu().numpy(), want_r, rtol=RTOL, atol=ATOL, err_msg=f"reward step {t}")
+        assert np.array_equal(wrapped.get_original_obs(), stacked)                 # raw stacks: bit-exact
+        assert np.array_equal(info["original_reward"].cpu().numpy(), raw_r)
+        if done.any():
+            n_done += int(done.sum())
+            np.testing.assert_allclose(info["terminal_observation"].cpu().numpy()[done], want_t[done], rtol=RTOL, atol=ATOL)
+        worst32 = max(worst32, float(np.abs(got_o - o32).max()))
+    assert n_done >= 2 * n                                                          # several resets per env (max_steps 23)
+    np.testing.assert_allclose(wrapped.obs_rms.mean, nz.obs_rms.mean, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(wrapped.obs_rms.var, nz.obs_rms.var, rtol=1e-9, atol=1e-12)
+    assert wrapped.obs_rms.count == pytest.approx(nz.obs_rms.count, rel=1e-12)
+    np.testing.assert_allclose(wrapped.ret_rms.mean, nz.ret_rms.mean, rtol=1e-9)
+    np.testing.assert_allclose(wrapped.ret_rms.var, nz.ret_rms.var, rtol=1e-9)
+    # float32 batch moments (what SB3 itself accumulates) move the normalised values by far less than the clip range
+    assert worst32 < 5e-3
+    wrapped.close()
+
+
+def test_frame_stack_alone_is_bit_exact_and_eval_mode_freezes_statistics(tmp_path):
+    from hlynr_intercept_amd.wrappers import VecFrameStack, VecNormalize
+    from oracle.vec_wrappers import FrameStack
+    n, T = 130, 40
+    obs0, steps, acts = _raw_trace(n, T)
+    env = _make(n)
+    st = VecFrameStack(env, n_stack=4)
+    fs = FrameStack(n, 26, 4)
+    assert np.array_equal(st.reset_torch().cpu().numpy(), fs.reset(obs0))
+    for t in range(T):
+        o, r, te, tr, info = st.step_torch(acts[t])
+        stacked, term = fs.step(steps[t][0], steps[t][2], steps[t][3])
+        assert np.array_equal(o.cpu().numpy(), stacked)
+        assert np.array_equal(r.cpu().numpy(), steps[t][1])
+        d = steps[t][2]
+        assert np.array_equal(info["terminal_observation"].cpu().numpy()[d], term[d])
+    st.close()
+
+    # VecNormalize: save -> load into a fresh env -> evaluation mode keeps the statistics and normalises identically
+    env = _make(n)
+    vn = VecNormalize(VecFrameStack(env, n_stack=4), norm_reward=False)
+    vn.reset_torch()
+    for t in range(10):
+        vn.step_torch(acts[t])
+    path = str(tmp_path / "vec_normalize.pkl")
+    vn.save(path)
+    mean, var, count = vn.obs_rms.mean.copy(), vn.obs_rms.var.copy(), vn.obs_rms.count
+    vn.training = False
+    o_eval = vn.step_torch(acts[10])[0].cpu().numpy().copy()
+    assert np.array_equal(vn.obs_rms.mean, mean) and vn.obs_rms.count == count
+    raw = vn.get_original_obs()
+    np.testing.assert_allclose(o_eval, vn.normalize_obs(raw), rtol=RTOL, atol=ATOL)
+    vn.close()
+    env2 = _make(n)
+    vn2 = VecNormalize.load(path, VecFrameStack(env2, n_stack=4))
+    assert np.array_equal(vn2.obs_rms.mean, mean) and np.array_equal(vn2.obs_rms.var, var) and vn2.obs_rms.count == count
+    vn2.training = False
+    vn2.reset_torch()
+    for t in range(11):
+        o2 = vn2.step_torch(acts[t])[0]
+    np.testing.assert_allclose(o2.cpu().numpy(), o_eval, rtol=RTOL, atol=ATOL)     # same env seed, same frozen statistics
+    vn2.close()
+
+
+def test_sb3_numpy_contract_of_the_wrapped_env():
+    from hlynr_intercept_amd.wrappers import VecFrameStack, VecNormalize
+    n = 48
+    env = VecNormalize(VecFrameStack(_make(n, max_steps=12), n_stack=4), norm_obs=True, norm_reward=False, clip_obs=10.0)
+    obs = env.reset()
+    assert obs.shape == (n, 104) and obs.dtype == np.float32
+    rng = np.random.default_rng(0)
+    seen_done = False
+    for t in range(30):
+        obs, rew, dones, infos = env.step(rng.uniform(-1, 1, (n, 6)).astype(np.float32))
+        assert obs.shape == (n, 104) and rew.shape == (n,) and dones.shape == (n,) and len(infos) == n
+        assert np.abs(obs).max() <= 10.0
+        for i, info in infos.done_items():
+            seen_done = True
+            assert info["terminal_observation"].shape == (104,) and "episode" in info
+    assert seen_done
+    env.env_method("set_training_step_count", 1234)                                 # passes through to the base env
+    assert env.get_attr("observation_generator")[0].radar_beam_width > 0
+    env.close()
