@@ -51,8 +51,21 @@ def cpu_baseline(rc, budget_s=12.0):
         ov.step(acts, sn, rn)
         steps += 1
     dt = time.perf_counter() - t0
-    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} envs x {steps} steps, medium scenario base physics, oracle/hlx_oracle.c with OpenMP over envs"}
+    out = {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{n} envs x {steps} steps, medium scenario base physics, oracle/hlx_oracle.c with OpenMP over envs"}
+    try:   # the same port on ONE thread (SURVEY.md 8(d) asks for both), ~3 s
+        import ctypes
+        gomp = ctypes.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(1)
+        t0, s1 = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 3.0:
+            ov.step(acts, sn, rn)
+            s1 += 1
+        out["single_thread_value"] = n * s1 / (time.perf_counter() - t0)
+        gomp.omp_set_num_threads(cores)
+    except OSError:
+        pass
+    return out
 
 
 def measured_traffic(physics, n):
