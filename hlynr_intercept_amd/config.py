@@ -14,6 +14,7 @@ from dataclasses import dataclass, field, asdict
 from typing import Any, Dict, List, Optional
 
 OBS_WORLD, OBS_BODY, OBS_LOS = 0, 1, 2
+MAX_VOLLEY = 4   # include/hlx.h HLX_MAX_VOLLEY
 _OBS_MODES = {"world_frame": OBS_WORLD, "body_frame": OBS_BODY, "los_frame": OBS_LOS}
 
 
@@ -118,6 +119,8 @@ class ResolvedConfig:
     ground_delay: int = 5             # samples; 0 = no delay ring
     weather_factor: float = 1.0       # environment.py:149 (never varied)
     obs_mode: int = OBS_WORLD
+    volley_mode: bool = False
+    volley_size: int = 1
 
     def to_dict(self) -> Dict[str, Any]:
         return asdict(self)
@@ -188,9 +191,12 @@ def resolve_config(config: Optional[Dict[str, Any]] = None) -> ResolvedConfig:
                                            "velocity": [[0, 0, 0], [50, 50, 20]]})
     rc.target_pos = [float(x) for x in config.get("target_position", [900, 900, 5])]
 
-    if config.get("volley_mode", False):
-        raise ConfigError("volley_mode (K>1 missiles per env) is not part of the batched step yet "
-                          "(SURVEY.md §8 f3)")
+    # volley mode (environment.py:42-43): K missiles per episode, spawned from the same ranges
+    rc.volley_mode = bool(config.get("volley_mode", False))
+    rc.volley_size = int(config.get("volley_size", 1))
+    if rc.volley_mode and not 1 <= rc.volley_size <= MAX_VOLLEY:
+        raise ConfigError(f"volley_size must be 1..{MAX_VOLLEY} (got {rc.volley_size}): the state arena holds "
+                          f"at most {MAX_VOLLEY} missiles per environment")
 
     # missile spawn (environment.py:376-415)
     rc.mis_pos_lo = [float(x) for x in ms["position"][0]]

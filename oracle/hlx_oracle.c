@@ -551,27 +551,34 @@ void orc_reset(const orc_config *c, orc_state *s, const double *nz, float *obs) 
     memset(s->g_ring, 0, sizeof s->g_ring); memset(s->g_pos_is64, 0, sizeof s->g_pos_is64);
     kf_reset(s);
     double tp[3] = {F(c->target_pos[0]), F(c->target_pos[1]), F(c->target_pos[2])};
-    /* missile (:389-435) */
-    double mp[3];
-    if (c->mis_spawn_spherical) {                                                /* :390-406 */
-        double radius = c->mis_radius[0] + (c->mis_radius[1] - c->mis_radius[0]) * nz[0];
-        double az = (c->mis_azimuth_deg[0] + (c->mis_azimuth_deg[1] - c->mis_azimuth_deg[0]) * nz[1]) * M_PI / 180.0;
-        double el = (c->mis_elevation_deg[0] + (c->mis_elevation_deg[1] - c->mis_elevation_deg[0]) * nz[2]) * M_PI / 180.0;
-        mp[0] = F(tp[0] + radius * cos(el) * cos(az));
-        mp[1] = F(tp[1] + radius * cos(el) * sin(az));
-        mp[2] = F(tp[2] + radius * sin(el));
-    } else {
-        for (int i = 0; i < 3; ++i) mp[i] = F(c->mis_pos_lo[i] + (c->mis_pos_hi[i] - c->mis_pos_lo[i]) * nz[i]); /* :409 */
+    /* missile(s) (:386-435): one, or volley_size of them, each with its own four draws in spawn order */
+    const int K = c->volley_mode ? c->volley_size : 1;
+    double mp[3];   /* missile 0 after the loop: `self.missile_state = self.missile_states[0]` (:439) */
+    for (int k = K - 1; k >= 0; --k) {   /* (descending only so that mp ends as missile 0; the draws are per-slot) */
+        const double *mz = k == 0 ? nz : nz + 32 + 4 * (k - 1);
+        if (c->mis_spawn_spherical) {                                            /* :390-406 */
+            double radius = c->mis_radius[0] + (c->mis_radius[1] - c->mis_radius[0]) * mz[0];
+            double az = (c->mis_azimuth_deg[0] + (c->mis_azimuth_deg[1] - c->mis_azimuth_deg[0]) * mz[1]) * M_PI / 180.0;
+            double el = (c->mis_elevation_deg[0] + (c->mis_elevation_deg[1] - c->mis_elevation_deg[0]) * mz[2]) * M_PI / 180.0;
+            mp[0] = F(tp[0] + radius * cos(el) * cos(az));
+            mp[1] = F(tp[1] + radius * cos(el) * sin(az));
+            mp[2] = F(tp[2] + radius * sin(el));
+        } else {
+            for (int i = 0; i < 3; ++i) mp[i] = F(c->mis_pos_lo[i] + (c->mis_pos_hi[i] - c->mis_pos_lo[i]) * mz[i]); /* :409 */
+        }
+        double speed = c->mis_speed[0] + (c->mis_speed[1] - c->mis_speed[0]) * mz[3]; /* :415 */
+        double tt[3];
+        for (int i = 0; i < 3; ++i) tt[i] = F(tp[i] - mp[i]);
+        double ttd = norm3(tt, 0);
+        for (int i = 0; i < 3; ++i) {
+            /* :421-423; the spawned-on-target fallback (:426) is unreachable for any box that excludes the target */
+            double v = (ttd > F(1e-6)) ? F(F(tt[i] / ttd) * F(speed)) : 0.0;
+            s->v_pos[k][i] = (float)mp[i]; s->v_vel[k][i] = (float)v;
+            if (k == 0) { s->mis_pos[i] = (float)mp[i]; s->mis_vel[i] = (float)v; }
+        }
+        s->v_active[k] = 1;
     }
-    double speed = c->mis_speed[0] + (c->mis_speed[1] - c->mis_speed[0]) * nz[3]; /* :415 */
-    double tt[3];
-    for (int i = 0; i < 3; ++i) tt[i] = F(tp[i] - mp[i]);
-    double ttd = norm3(tt, 0);
-    for (int i = 0; i < 3; ++i) {
-        /* :421-423; the spawned-on-target fallback (:426) is unreachable for any box that excludes the target */
-        double v = (ttd > F(1e-6)) ? F(F(tt[i] / ttd) * F(speed)) : 0.0;
-        s->mis_pos[i] = (float)mp[i]; s->mis_vel[i] = (float)v;
-    }
+    s->prio = 0; s->n_intercepted = 0;
     /* interceptor (:442-467) */
     double ipos[3];
     for (int i = 0; i < 3; ++i) ipos[i] = F(c->int_pos_lo[i] + (c->int_pos_hi[i] - c->int_pos_lo[i]) * nz[4 + i]);
@@ -585,11 +592,24 @@ void orc_reset(const orc_config *c, orc_state *s, const double *nz, float *obs) 
     } else {
         for (int i = 0; i < 3; ++i) ivel[i] = F(c->int_vel_lo[i] + (c->int_vel_hi[i] - c->int_vel_lo[i]) * nz[7 + i]); /* :467 */
     }
+    /* volley: per-missile minimum distances (:469-473); the interceptor points at the CLOSEST missile (:476-487),
+     * while the first observation and _prev_distance use missile 0 (:439, :579) */
+    double orel[3] = {rel[0], rel[1], rel[2]}, oreld = reld;
+    if (c->volley_mode) {
+        double best = INFINITY;
+        for (int k = 0; k < K; ++k) {
+            double r[3];
+            for (int i = 0; i < 3; ++i) r[i] = F((double)s->v_pos[k][i] - ipos[i]);
+            double dk = norm3(r, 0);
+            s->v_min[k] = (float)dk;
+            if (dk < best) { best = dk; oreld = dk; for (int i = 0; i < 3; ++i) orel[i] = r[i]; }
+        }
+    }
     /* initial orientation: rotate +Z onto the LOS (:489-530), float64 until the final cast */
     double quat[4] = {1.0, 0.0, 0.0, 0.0};
-    if (reld > F(1e-6)) {
+    if (oreld > F(1e-6)) {
         double fd[3];
-        for (int i = 0; i < 3; ++i) fd[i] = F(rel[i] / reld);
+        for (int i = 0; i < 3; ++i) fd[i] = F(orel[i] / oreld);
         double ax[3] = {-fd[1], fd[0], 0.0};
         double axl = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
         double cosang = fd[2];
@@ -725,13 +745,17 @@ void orc_step(const orc_config *c, orc_state *s, const float *action, const doub
         for (int i = 0; i < 4; ++i) s->int_quat[i] = (float)F(r[i] / n);
     }
 
-    /* ---- _update_missile_state  environment.py:1069-1117 ---- */
-    {
-        double malt = s->mis_pos[2] > 0.0f ? (double)s->mis_pos[2] : 0.0;
+    /* ---- _update_missile_state  environment.py:1069-1117 (every ACTIVE missile of a volley, :631-636) ---- */
+    const int K = c->volley_mode ? c->volley_size : 1;
+    for (int km = 0; km < K; ++km) {
+        float *mpos = c->volley_mode ? s->v_pos[km] : s->mis_pos, *mvel = c->volley_mode ? s->v_vel[km] : s->mis_vel;
+        const double *ez = km == 0 ? nz : nz + 20 + 3 * (km - 1);   /* this missile's evasion draws */
+        if (c->volley_mode && !s->v_active[km]) continue;
+        double malt = mpos[2] > 0.0f ? (double)mpos[2] : 0.0;
         double mrho = 1.225, msos = 343.0;
         if (c->atmosphere) atmosphere(malt, s->T0, &mrho, &msos);
         double mva[3], md[3];
-        for (int i = 0; i < 3; ++i) mva[i] = rr((double)s->mis_vel[i] - s->wind[i], w64);
+        for (int i = 0; i < 3; ++i) mva[i] = rr((double)mvel[i] - s->wind[i], w64);
         if (c->mach_drag && norm3(mva, w64) > rr(1e-6, w64)) {
             double f[3];
             mach_drag_force(c, s, mva, w64, mrho, msos, 2.0, f);
@@ -740,13 +764,13 @@ void orc_step(const orc_config *c, orc_state *s, const float *action, const doub
         } else simple_drag_accel(c, mva, w64, mrho, 1000.0, md);
         double macc[3];
         for (int i = 0; i < 3; ++i) {
-            double ev = c->evasion ? nz[i] * 2.0 : 0.0;                          /* :1103-1105 */
+            double ev = c->evasion ? ez[i] * 2.0 : 0.0;                          /* :1103-1105 */
             macc[i] = rr(md[i] + grav[i], w64) + ev;                             /* :1108 -> float64 */
         }
         if (c->validation) nan_guard(macc, 20.0);
         for (int i = 0; i < 3; ++i) {                                            /* :1116-1117 */
-            s->mis_vel[i] = (float)F((double)s->mis_vel[i] + macc[i] * dt);
-            s->mis_pos[i] = (float)F((double)s->mis_pos[i] + F((double)s->mis_vel[i] * dtf));
+            mvel[i] = (float)F((double)mvel[i] + macc[i] * dt);
+            mpos[i] = (float)F((double)mpos[i] + F((double)mvel[i] * dtf));
         }
     }
 
@@ -786,12 +810,39 @@ void orc_step(const orc_config *c, orc_state *s, const float *action, const doub
         s->wind_is64 = 1;
     }
 
+    /* ---- volley: priority missile = closest active one, first wins ties, missile 0 if none is active (:236-267,
+     * :643-650); from here on it is `self.missile_state` (observation, reward alignment, next step's LOS frame) ---- */
+    double vdist[ORC_MAX_VOLLEY] = {0, 0, 0, 0};
+    if (c->volley_mode) {
+        int sel = -1;
+        double best = 0.0;
+        for (int k = 0; k < K; ++k) {
+            double r[3];
+            for (int i = 0; i < 3; ++i) r[i] = F((double)s->v_pos[k][i] - (double)s->int_pos[i]);
+            vdist[k] = norm3(r, 0);
+            if (s->v_active[k] && (sel < 0 || vdist[k] < best)) { sel = k; best = vdist[k]; }
+        }
+        s->prio = sel < 0 ? 0 : sel;
+        for (int i = 0; i < 3; ++i) { s->mis_pos[i] = s->v_pos[s->prio][i]; s->mis_vel[i] = s->v_vel[s->prio][i]; }
+    }
     /* ---- intercept / termination  environment.py:657-814 ---- */
     double rel[3];
     for (int i = 0; i < 3; ++i) rel[i] = F((double)s->mis_pos[i] - (double)s->int_pos[i]);
     double distance = norm3(rel, 0);
     int intercepted;
-    if (c->proximity_fuze) intercepted = distance < F(c->proximity_kill_radius);  /* :700-703 */
+    if (c->volley_mode) {                                                        /* :661-692 */
+        const double thr = c->proximity_fuze ? F(c->proximity_kill_radius) : F(c->intercept_radius);
+        intercepted = 0;
+        for (int k = 0; k < K; ++k) {
+            if (!s->v_active[k]) continue;
+            if (vdist[k] < (double)s->v_min[k]) s->v_min[k] = (float)vdist[k];
+            if (vdist[k] < thr) { intercepted = 1; s->n_intercepted += 1; s->v_active[k] = 0; }
+        }
+        int any = 0;
+        distance = 0.0;                                                          /* :691: 0.0 when nothing is left */
+        for (int k = 0; k < K; ++k)
+            if (s->v_active[k] && (!any || vdist[k] < distance)) { distance = vdist[k]; any = 1; }
+    } else if (c->proximity_fuze) intercepted = distance < F(c->proximity_kill_radius);  /* :700-703 */
     else intercepted = distance < F(c->intercept_radius);
     if (distance < (double)s->min_distance) s->min_distance = (float)distance;   /* :706 */
     if (intercepted && !s->crossed) s->crossed = 1;                              /* :709-710 */
@@ -801,7 +852,19 @@ void orc_step(const orc_config *c, orc_state *s, const float *action, const doub
     int ground = s->mis_pos[2] <= 0.0f;
     double gd2[3] = {F((double)s->mis_pos[0] - F(c->target_pos[0])), F((double)s->mis_pos[1] - F(c->target_pos[1])), 0.0};
     int near_target = F(sqrt(F(F(gd2[0] * gd2[0]) + F(gd2[1] * gd2[1])))) < F(500.0);
-    if (c->precision_mode) {                                                     /* :752-767 */
+    if (c->volley_mode) {                                                        /* :724-748 */
+        int all_inactive = 1;
+        for (int k = 0; k < K; ++k) {
+            if (s->v_pos[k][2] <= 0.0f) {                                        /* on the ground: neutralised, whoever it was */
+                s->v_active[k] = 0;
+                double g0 = F((double)s->v_pos[k][0] - F(c->target_pos[0])), g1 = F((double)s->v_pos[k][1] - F(c->target_pos[1]));
+                if (F(sqrt(F(F(g0 * g0) + F(g1 * g1)))) < F(500.0)) hit_target = 1;
+            }
+            if (s->v_active[k]) all_inactive = 0;
+        }
+        if (all_inactive) terminated = 1;
+        else if (fuze) terminated = 1;
+    } else if (c->precision_mode) {                                              /* :752-767 */
         if (ground) { terminated = 1; if (near_target) hit_target = 1; }
     } else {                                                                     /* :769-786 */
         if (intercepted) terminated = 1;
@@ -887,6 +950,14 @@ void orc_step(const orc_config *c, orc_state *s, const float *action, const doub
     out->terminated = terminated; out->truncated = truncated; out->intercepted = intercepted;
     out->hit_target = hit_target; out->fuze_triggered = fuze; out->clamped = clamped;
     out->distance = (float)distance; out->min_distance = s->min_distance;
+    if (c->volley_mode) {                                                        /* :846-847 */
+        out->missiles_intercepted = s->n_intercepted;
+        out->missiles_remaining = 0;
+        for (int k = 0; k < K; ++k) out->missiles_remaining += s->v_active[k] != 0;
+    } else {
+        out->missiles_intercepted = intercepted ? 1 : 0;
+        out->missiles_remaining = intercepted ? 0 : 1;
+    }
 }
 
 /* ------------------------------------------------------------------------------------------

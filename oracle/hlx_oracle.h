@@ -23,8 +23,9 @@
 extern "C" {
 #endif
 
-#define ORC_STEP_SLOTS 20
-#define ORC_RESET_SLOTS 32
+#define ORC_STEP_SLOTS 32   /* 0-19 as documented; 20+3(k-1).. evasion normals of volley missile k >= 1 */
+#define ORC_RESET_SLOTS 48  /* 0-31 as documented; 32+4(k-1).. spawn uniforms (position x3, speed) of volley missile k >= 1 */
+#define ORC_MAX_VOLLEY 4
 #define ORC_MAX_DELAY 10
 #define ORC_RING_CAP (ORC_MAX_DELAY + 1)
 
@@ -54,6 +55,7 @@ typedef struct {
     int32_t ground_delay;
     double weather_factor;
     int32_t obs_mode; /* 0 world, 1 body, 2 los */
+    int32_t volley_mode, volley_size; /* environment.py:42-43: K missiles per episode (K <= ORC_MAX_VOLLEY) */
     /* per-vec-step curriculum scalars (host evaluates the schedules) */
     double intercept_radius, beam_width_deg, onboard_reliability, ground_reliability;
 } orc_config;
@@ -83,6 +85,12 @@ typedef struct {
     double T0, base_cd, transonic_peak;
     double total_fuel_used;
     int32_t structure_violations; /* KF covariance left the 3x(2x2) block structure / S not diagonal */
+    /* volley mode (environment.py:44, 370-373): every missile of the volley; mis_pos / mis_vel above are the
+     * reference's `self.missile_state`, i.e. the entry `prio` of this list (re-selected every step, :643-650) */
+    float v_pos[ORC_MAX_VOLLEY][3], v_vel[ORC_MAX_VOLLEY][3];
+    int32_t v_active[ORC_MAX_VOLLEY];
+    float v_min[ORC_MAX_VOLLEY];        /* missile_min_distances */
+    int32_t prio, n_intercepted;        /* index of self.missile_state; len(intercepted_missile_indices) */
 } orc_state;
 
 typedef struct {
@@ -90,6 +98,7 @@ typedef struct {
     double reward;
     int32_t terminated, truncated, intercepted, hit_target, fuze_triggered, clamped;
     float distance, min_distance;
+    int32_t missiles_intercepted, missiles_remaining;   /* info (:846-847) */
 } orc_out;
 
 /* constructor state (T0, drag constants, onboard delay): call once per env before the first reset */
@@ -102,10 +111,10 @@ void orc_step(const orc_config *cfg, orc_state *st, const float *action6, const 
 /* Batched helpers (array-of-struct state; OpenMP over envs when built with -fopenmp).
  * step_batch applies VecEnv auto-reset semantics: on done, terminal obs is written to
  * terminal_obs[i] and the env is reset with reset_noise[i]. */
-void orc_reset_batch(const orc_config *cfg, orc_state *st, int32_t n, const double *noise /*[n][32]*/,
+void orc_reset_batch(const orc_config *cfg, orc_state *st, int32_t n, const double *noise /*[n][ORC_RESET_SLOTS]*/,
                      float *obs /*[n][26]*/);
 void orc_step_batch(const orc_config *cfg, orc_state *st, int32_t n, const float *actions /*[n][6]*/,
-                    const double *step_noise /*[n][20]*/, const double *reset_noise /*[n][32]*/,
+                    const double *step_noise /*[n][ORC_STEP_SLOTS]*/, const double *reset_noise /*[n][ORC_RESET_SLOTS]*/,
                     orc_out *out /*[n]*/, float *terminal_obs /*[n][26]*/, int32_t auto_reset);
 int32_t orc_sizeof_state(void);
 int32_t orc_sizeof_config(void);

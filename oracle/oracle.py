@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-STEP_SLOTS, RESET_SLOTS, RING_CAP = 20, 32, 11
+STEP_SLOTS, RESET_SLOTS, RING_CAP, MAX_VOLLEY = 32, 48, 11, 4
 
 d, i32, f32 = C.c_double, C.c_int32, C.c_float
 
@@ -35,7 +35,7 @@ class OrcConfig(C.Structure):
         ("ground_pos", d * 3), ("ground_max_range", d), ("ground_min_elev", d), ("ground_max_elev", d),
         ("ground_range_accuracy", d), ("ground_velocity_accuracy", d), ("ground_base_quality", d),
         ("max_datalink_range", d), ("datalink_packet_loss", d), ("ground_delay", i32), ("weather_factor", d),
-        ("obs_mode", i32),
+        ("obs_mode", i32), ("volley_mode", i32), ("volley_size", i32),
         ("intercept_radius", d), ("beam_width_deg", d), ("onboard_reliability", d), ("ground_reliability", d),
     ]
 
@@ -53,6 +53,8 @@ class OrcState(C.Structure):
         ("g_count", i32), ("g_len", i32), ("g_ring", (d * 7) * RING_CAP), ("g_pos_is64", i32 * RING_CAP),
         ("T0", d), ("base_cd", d), ("transonic_peak", d), ("total_fuel_used", d),
         ("structure_violations", i32),
+        ("v_pos", (f32 * 3) * MAX_VOLLEY), ("v_vel", (f32 * 3) * MAX_VOLLEY), ("v_active", i32 * MAX_VOLLEY),
+        ("v_min", f32 * MAX_VOLLEY), ("prio", i32), ("n_intercepted", i32),
     ]
 
 
@@ -61,13 +63,15 @@ class OrcOut(C.Structure):
         ("obs", f32 * 26), ("reward", d),
         ("terminated", i32), ("truncated", i32), ("intercepted", i32), ("hit_target", i32),
         ("fuze_triggered", i32), ("clamped", i32), ("distance", f32), ("min_distance", f32),
+        ("missiles_intercepted", i32), ("missiles_remaining", i32),
     ]
 
 
 OUT_DTYPE = np.dtype([("obs", np.float32, 26), ("reward", np.float64), ("terminated", np.int32),
                       ("truncated", np.int32), ("intercepted", np.int32), ("hit_target", np.int32),
                       ("fuze_triggered", np.int32), ("clamped", np.int32), ("distance", np.float32),
-                      ("min_distance", np.float32)], align=True)
+                      ("min_distance", np.float32), ("missiles_intercepted", np.int32),
+                      ("missiles_remaining", np.int32)], align=True)
 
 _lib = None
 

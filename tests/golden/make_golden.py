@@ -41,6 +41,10 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 
 N_STEP_SLOTS = 20
 N_RESET_SLOTS = 32
+# volley fixtures (K <= 4 missiles) use the extended layout: missile k >= 1 draws its evasion normals into step slots
+# 20+3(k-1) .. and its spawn uniforms (position x3, speed) into reset slots 32+4(k-1) ..
+V_STEP_SLOTS = 32
+V_RESET_SLOTS = 48
 
 
 # --------------------------------------------------------------------------------------
@@ -77,9 +81,12 @@ class Tape:
         self.mode = "reset"
         self.clear()
 
+    volley = False
+    cur_missile = 0
+
     def clear(self):
-        self.step = np.full(N_STEP_SLOTS, np.nan)
-        self.reset = np.full(N_RESET_SLOTS, np.nan)
+        self.step = np.full(V_STEP_SLOTS if self.volley else N_STEP_SLOTS, np.nan)
+        self.reset = np.full(V_RESET_SLOTS if self.volley else N_RESET_SLOTS, np.nan)
         self._reset_uniform_calls = 0
         self._ground_normal_calls = 0
         self._wind_normal_calls = 0
@@ -174,7 +181,8 @@ def _rec_randn(*shape):
     z = np.random.standard_normal(shape)
     who = _caller()
     if who == "_update_missile_state":
-        TAPE.put("step", 0, z)
+        k = TAPE.cur_missile
+        TAPE.put("step", 0 if k == 0 else 20 + 3 * (k - 1), z)
     elif who == "_update_wind":
         TAPE.put("step", 3, z)
     else:
@@ -252,6 +260,12 @@ def capture_state(env):
         kf_x_is64=np.int64(kf.state.dtype == np.float64), kf_P=np.array(kf.P, np.float64),
         total_fuel_used=np.float64(env.total_fuel_used),
     )
+    if getattr(env, "volley_mode", False):
+        ms = env.missile_states
+        s.update(v_pos=np.array([m["position"] for m in ms], np.float64), v_vel=np.array([m["velocity"] for m in ms], np.float64),
+                 v_active=np.array([bool(m["active"]) for m in ms], np.int64),
+                 v_min=np.array(env.missile_min_distances, np.float64),
+                 prio=np.int64([i for i, m in enumerate(ms) if m is env.missile_state][0]))
     on = ring_dump(og.sensor_delay_buffer, 3, lambda m: m["rel_pos"])
     gr = ring_dump(og.ground_sensor_delay_buffer, 7,
                    lambda m: np.concatenate([m["rel_pos"], m["rel_vel"], [m["quality"]]]))
@@ -365,6 +379,23 @@ def run_case(name, env_cfg, n_steps, seed, policy="random", tweak=None, global_s
     if global_step:
         env.set_training_step_count(global_step)
     arng = _orig_default_rng(seed + 77)
+    TAPE.volley = bool(env.volley_mode)
+    K = int(env.volley_size) if env.volley_mode else 1
+    if env.volley_mode:
+        # tell the evasion recorder which missile a draw belongs to (only active missiles draw: environment.py:632-636)
+        inner = env._update_missile_state
+
+        def tagged(missile_state):
+            TAPE.cur_missile = [i for i, m in enumerate(env.missile_states) if m is missile_state][0]
+            try:
+                return inner(missile_state)
+            finally:
+                TAPE.cur_missile = 0
+
+        def _update_missile_state(missile_state):   # name matters: the recorder asserts on its caller's name
+            return tagged(missile_state)
+
+        env._update_missile_state = _update_missile_state
 
     def do_reset(s):
         TAPE.clear()
@@ -376,15 +407,17 @@ def run_case(name, env_cfg, n_steps, seed, policy="random", tweak=None, global_s
         spherical = env.missile_spawn_range.get("position_mode", "box") == "spherical"
         slots = TAPE.reset
         idx = 0
-        if spherical:
-            for j in range(3):
-                slots[j] = calls[idx][1][0]
+        for k in range(K):                       # per missile: position (1 vector or 3 scalar calls), then speed
+            base = 0 if k == 0 else 32 + 4 * (k - 1)
+            if spherical:
+                for j in range(3):
+                    slots[base + j] = calls[idx][1][0]
+                    idx += 1
+            else:
+                slots[base:base + 3] = calls[idx][1]
                 idx += 1
-        else:
-            slots[0:3] = calls[idx][1]
+            slots[base + 3] = calls[idx][1][0]
             idx += 1
-        slots[3] = calls[idx][1][0]
-        idx += 1
         slots[4:7] = calls[idx][1]
         idx += 1
         last = calls[idx][1]
@@ -401,6 +434,7 @@ def run_case(name, env_cfg, n_steps, seed, policy="random", tweak=None, global_s
     init_state = capture_state(env)
     rec = dict(action=[], step_noise=[], obs=[], reward=[], terminated=[], truncated=[], distance=[],
                intercepted=[], hit_target=[], info_min_distance=[], fuel_used=[], state=[],
+               missiles_intercepted=[], missiles_remaining=[], missile_min_distances=[],
                did_reset=[], reset_noise=[], reset_obs=[], reset_state=[], radius=[], st_index=[])
     for t in range(n_steps):
         if policy == "random":
@@ -433,6 +467,10 @@ def run_case(name, env_cfg, n_steps, seed, policy="random", tweak=None, global_s
         rec["info_min_distance"].append(np.float64(info["min_distance"]))
         rec["fuel_used"].append(np.float64(info["fuel_used"]))
         rec["radius"].append(np.float64(env.get_current_intercept_radius()))
+        if env.volley_mode:
+            rec["missiles_intercepted"].append(np.int64(info["missiles_intercepted"]))
+            rec["missiles_remaining"].append(np.int64(info["missiles_remaining"]))
+            rec["missile_min_distances"].append(np.array(info["missile_min_distances"], np.float64))
         if t % state_every == 0 or term or trunc or t == n_steps - 1:
             # full post-step state (long cases keep every `state_every`-th one to stay small)
             rec["state"].append(capture_state(env))
@@ -468,6 +506,7 @@ def run_case(name, env_cfg, n_steps, seed, policy="random", tweak=None, global_s
         ground_enabled=gr is not None,
         ground_delay=og.ground_sensor_delay_buffer.delay_samples if og.ground_sensor_delay_buffer else 0,
         obs_mode=og.observation_mode,
+        volley_size=(int(env.volley_size) if env.volley_mode else 0),
     )
     if gr is not None:
         effective.update(ground_pos=[float(x) for x in gr.position], ground_max_range=gr.max_range,
@@ -494,6 +533,10 @@ def run_case(name, env_cfg, n_steps, seed, policy="random", tweak=None, global_s
     for k in ("action", "step_noise", "obs", "reward", "terminated", "truncated", "distance", "intercepted",
               "hit_target", "info_min_distance", "fuel_used", "did_reset", "radius", "st_index"):
         out[k] = np.array(rec[k])
+    if env.volley_mode:
+        out["volley_size"] = np.int64(K)
+        for k in ("missiles_intercepted", "missiles_remaining", "missile_min_distances"):
+            out[k] = np.array(rec[k])
     for k, v in stack_states(rec["state"]).items():
         out["st_" + k] = v
     if rec["reset_state"]:
@@ -505,7 +548,7 @@ def run_case(name, env_cfg, n_steps, seed, policy="random", tweak=None, global_s
     for k in list(out.keys()):
         v = out[k]
         if isinstance(v, np.ndarray) and v.dtype == np.float64 and k.split("_", 1)[-1] in (
-                "int_pos", "int_vel", "int_quat", "mis_pos", "mis_vel", "wind", "thrust_actual", "kf_P"):
+                "int_pos", "int_vel", "int_quat", "mis_pos", "mis_vel", "wind", "thrust_actual", "kf_P", "v_pos", "v_vel"):
             if np.array_equal(v.astype(np.float32).astype(np.float64), v, equal_nan=True):
                 out[k] = v.astype(np.float32)  # (simple-wind `wind` is float64 in the reference: kept as is)
     n_ep = int(np.sum(out["did_reset"]))
@@ -589,11 +632,14 @@ def main():
     np.random.uniform = _rec_uniform
     np.random.randn = _rec_randn
     _selfcheck_wrappers()
+    S = scenario_config
+    if len(sys.argv) > 1 and sys.argv[1] == "volley":
+        volley_cases(S)      # adds / refreshes the volley fixtures only
+        return
     for f in os.listdir(OUT):
         if f.endswith(".npz"):
             os.remove(os.path.join(OUT, f))
 
-    S = scenario_config
     # --- scenario x physics, random actions -------------------------------------------
     run_case("easy_config_random", S("easy", "config"), 300, 1000)
     run_case("medium_base_random", S("medium", "base"), 400, 1001)
@@ -650,6 +696,54 @@ def main():
     run_case("edge_radar_curriculum_mid", S("medium", "base"), 120, 1061, global_step=6500000,
              policy=spin_then_random)
     run_case("edge_no_ground_radar", S("medium", "base", {"ground_radar": {"enabled": False}}), 100, 1062)
+    volley_cases(S)
+
+
+def tw_volley_ground(env):
+    # missile 1 about to hit the ground next to the target (mission failure), missile 2 far from it (harmless)
+    ms = env.missile_states
+    ms[1]["position"][:] = np.array([130.0, 80.0, 5.0], np.float32)
+    ms[1]["velocity"][:] = np.array([-40.0, -30.0, -70.0], np.float32)
+    ms[2]["position"][:] = np.array([1400.0, 900.0, 9.0], np.float32)
+    ms[2]["velocity"][:] = np.array([-40.0, -30.0, -50.0], np.float32)
+
+
+def tw_volley_close(env):
+    # interceptor right behind the volley: several intercepts within a few steps
+    ms = env.missile_states
+    c = ms[0]["position"].copy()
+    for k, m in enumerate(ms[1:], 1):
+        m["position"][:] = c + np.array([25.0 * k, -20.0 * k, 15.0 * k], np.float32)
+        m["velocity"][:] = ms[0]["velocity"]
+    env.interceptor_state["position"][:] = c - np.array([150.0, 120.0, 100.0], np.float32)
+    env.interceptor_state["velocity"][:] = np.array([200.0, 160.0, 120.0], np.float32)
+    ip = env.interceptor_state["position"]
+    env.missile_min_distances[:] = [np.linalg.norm(m["position"] - ip) for m in ms]
+    d = np.linalg.norm(ms[0]["position"] - ip)
+    env._prev_distance = np.float32(d)
+    env._last_distance = env._prev_distance
+    env._episode_min_distance = env._prev_distance
+
+
+def volley_cases(S):
+    """Volley mode (environment.py:236-267, 386-439, 470-487, 631-692, 724-748): K missiles per environment."""
+    V = lambda k, extra=None: dict({"volley_mode": True, "volley_size": k}, **(extra or {}))  # noqa: E731
+    run_case("volley3_medium_base_random", S("medium", "base", V(3)), 400, 1100)
+    run_case("volley3_medium_base_pursuit", S("medium", "base", V(3)), 2500, 1101, policy="pursuit", state_every=25)
+    run_case("volley3_medium_v2_fuze_pursuit", S("medium", "v2", V(3, {"proximity_fuze_enabled": True,
+                                                                      "proximity_kill_radius": 30.0})), 2500, 1102,
+             policy="pursuit", state_every=25)
+    run_case("volley2_medium_v2_los_pursuit", S("medium", "v2", V(2, {"observation_mode": "los_frame"})), 1500, 1103,
+             policy="pursuit", state_every=25)
+    run_case("volley4_medium_v2dr_short_eps", S("medium", "v2dr", V(4, {"max_steps": 50})), 300, 1104)
+    run_case("volley3_edge_ground_hits", S("medium", "base", V(3)), 60, 1105, tweak=tw_volley_ground)
+    run_case("volley3_edge_close_intercepts", S("medium", "base", V(3)), 120, 1106, tweak=tw_volley_close, policy="coast")
+    ev = load_yaml("configs/eval_360_los.yaml")
+    ec = copy.deepcopy(ev["environment"])
+    ec["curriculum"] = copy.deepcopy(ev["curriculum"])
+    ec["physics_enhancements"] = copy.deepcopy(ev["physics_enhancements"])
+    ec.update(V(3))
+    run_case("volley3_eval360_spherical_pursuit", ec, 1500, 1107, policy="pursuit", state_every=25)
 
 
 if __name__ == "__main__":

@@ -42,6 +42,15 @@ def inject_initial_state(st, fx):
     st.last_distance = float(fx["init_last_distance"])
     st.worsening = int(fx["init_worsening"])
     st.crossed = int(fx["init_crossed"])
+    if "init_v_pos" in fx:   # volley fixtures: every missile (the tweaks move them individually)
+        K = fx["init_v_pos"].shape[0]
+        for k in range(K):
+            for i in range(3):
+                st.v_pos[k][i] = float(fx["init_v_pos"][k][i])
+                st.v_vel[k][i] = float(fx["init_v_vel"][k][i])
+            st.v_active[k] = int(fx["init_v_active"][k])
+            st.v_min[k] = float(fx["init_v_min"][k])
+        st.prio = int(fx["init_prio"])
 
 
 def state_errors(st, ref, idx=None):
@@ -75,6 +84,15 @@ def state_errors(st, ref, idx=None):
     errs["transonic_peak"] = rel(st.transonic_peak, g("transonic_peak"), 1.0)
     ints = dict(steps=st.steps, worsening=st.worsening, crossed=st.crossed, kf_init=st.kf_init,
                 kf_x_is64=st.kf_x_is64, on_count=st.on_count, g_count=st.g_count)
+    if "v_pos" in ref:   # volley: all missiles, their activity, per-missile minimum distances, the priority index
+        K = g("v_pos").shape[0]
+        errs["v_pos"] = rel([list(st.v_pos[k]) for k in range(K)], g("v_pos"), 1.0)
+        errs["v_vel"] = rel([list(st.v_vel[k]) for k in range(K)], g("v_vel"), 1.0)
+        errs["v_min"] = rel([st.v_min[k] for k in range(K)], g("v_min"), 1.0)
+        act = [int(st.v_active[k] != 0) for k in range(K)]
+        if act != [int(x) for x in g("v_active")]:
+            errs["INT_v_active"] = (act, [int(x) for x in g("v_active")])
+        ints["prio"] = st.prio
     for k, v in ints.items():
         if int(v) != int(g(k)):
             errs["INT_" + k] = (int(v), int(g(k)))
@@ -144,6 +162,11 @@ def replay_oracle(fx, collect=None):
                      bool(fx["hit_target"][t]))
         if flags != ref_flags:
             res["flag_mismatch"].append((t, flags, ref_flags))
+        if "missiles_intercepted" in fx:
+            got = (int(out.missiles_intercepted), int(out.missiles_remaining))
+            want = (int(fx["missiles_intercepted"][t]), int(fx["missiles_remaining"][t]))
+            if got != want:
+                res["flag_mismatch"].append((t, "missiles", got, want))
         if collect is not None:
             collect(t, o, out)
         if t in st_pos:

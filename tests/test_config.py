@@ -88,6 +88,9 @@ def test_curriculum_schedules():
     assert rc.radar_schedule(9_000_000)["beam_width"] == 60.0
 
 
-def test_unsupported_configurations_fail_loudly():
-    with pytest.raises(ConfigError):
-        resolve_config({"volley_mode": True, "volley_size": 3})
+def test_volley_mode_is_carried_and_oversized_volleys_fail_loudly():
+    rc = resolve_config({"volley_mode": True, "volley_size": 3})          # environment.py:42-43
+    assert rc.volley_mode and rc.volley_size == 3
+    assert not resolve_config({}).volley_mode
+    with pytest.raises(ConfigError):                                       # the arena holds at most 4 missiles per env
+        resolve_config({"volley_mode": True, "volley_size": 5})
