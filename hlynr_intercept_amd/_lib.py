@@ -12,13 +12,14 @@ from . import build as _build
 
 f32, i32, u32, i64, u64, f64, u8p = C.c_float, C.c_int32, C.c_uint32, C.c_int64, C.c_uint64, C.c_double, C.c_void_p
 
-OBS_DIM, ACT_DIM, STEP_SLOTS, RESET_SLOTS, RING_CAP, MAX_STEPS = 26, 6, 20, 32, 11, 8191
+OBS_DIM, ACT_DIM, STEP_SLOTS, RESET_SLOTS, RING_CAP, MAX_STEPS, MAX_VOLLEY = 26, 6, 32, 48, 11, 8191, 4
 
 # hlx_flags
 F_ATMOSPHERE, F_MACH_DRAG, F_ENH_WIND, F_THRUST_LAG, F_DOMAIN_RAND, F_VALIDATION, F_EVASION, F_PRECISION = (
     1 << 0, 1 << 1, 1 << 2, 1 << 3, 1 << 4, 1 << 5, 1 << 6, 1 << 7)
 F_PROX_FUZE, F_GROUND, F_SPHERICAL, F_TOWARD_MISSILE, F_OBS_BODY, F_OBS_LOS, F_USE_CURRICULUM, F_RADAR_CURRICULUM = (
     1 << 8, 1 << 9, 1 << 10, 1 << 11, 1 << 12, 1 << 13, 1 << 14, 1 << 15)
+F_VOLLEY = 1 << 16
 
 
 class HlxConfig(C.Structure):
@@ -40,12 +41,13 @@ class HlxConfig(C.Structure):
         ("max_datalink_range", f64), ("datalink_packet_loss", f64), ("weather_factor", f64),
         ("initial_radius", f64), ("final_radius", f64), ("curriculum_steps", f64),
         ("rc_beam", f64 * 4), ("rc_onboard", f64 * 4), ("rc_ground", f64 * 4), ("rc_noise", f64 * 4),
+        ("volley_size", i32), ("pad1", i32),
     ]
 
 
 class HlxInfoSoa(C.Structure):
     _fields_ = [("distance", C.c_void_p), ("min_distance", C.c_void_p), ("fuel", C.c_void_p), ("flags", C.c_void_p),
-                ("episode_return", C.c_void_p), ("episode_length", C.c_void_p)]
+                ("episode_return", C.c_void_p), ("episode_length", C.c_void_p), ("missiles", C.c_void_p)]
 
 
 class HlxEnvState(C.Structure):
@@ -58,6 +60,8 @@ class HlxEnvState(C.Structure):
         ("on_delay", i32), ("on_len", i32), ("on_ring", (f32 * 4) * RING_CAP),
         ("g_len", i32), ("g_ring", (f64 * 8) * RING_CAP),
         ("T0", f32), ("base_cd", f32), ("transonic_peak", f32), ("ep_return", f32),
+        ("v_pos", (f32 * 3) * MAX_VOLLEY), ("v_vel", (f32 * 3) * MAX_VOLLEY), ("v_min", f32 * MAX_VOLLEY),
+        ("v_active", i32 * MAX_VOLLEY), ("prio", i32), ("n_intercepted", i32),
     ]
 
 
@@ -155,10 +159,12 @@ def make_hlx_config(rc) -> HlxConfig:
                       (rc.proximity_fuze, F_PROX_FUZE), (rc.ground_enabled, F_GROUND),
                       (rc.mis_spawn_spherical, F_SPHERICAL), (rc.int_vel_toward_missile, F_TOWARD_MISSILE),
                       (rc.obs_mode == 1, F_OBS_BODY), (rc.obs_mode == 2, F_OBS_LOS),
-                      (rc.use_curriculum, F_USE_CURRICULUM), (rc.radar_curriculum.active, F_RADAR_CURRICULUM)):
+                      (rc.use_curriculum, F_USE_CURRICULUM), (rc.radar_curriculum.active, F_RADAR_CURRICULUM),
+                      (rc.volley_mode, F_VOLLEY)):
         if cond:
             flags |= bit
     c.flags = flags
+    c.volley_size = int(rc.volley_size) if rc.volley_mode else 1
     simple = ("max_steps", "dt", "max_range", "max_velocity", "subsonic_mach", "supersonic_mach",
               "transonic_peak_multiplier", "supersonic_multiplier", "wind_variability", "boundary_layer_height",
               "turbulence_intensity", "gust_scale", "thrust_tau", "proximity_kill_radius", "radar_quality",

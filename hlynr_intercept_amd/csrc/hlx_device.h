@@ -161,7 +161,9 @@ enum : uint32_t {
     RS_STEP_U = 0, RS_STEP_N0 = 1, RS_STEP_N1 = 2, RS_STEP_N2 = 3, RS_GUST = 5,
     // step normals: N0 = evasion xyz + wind x, N1 = wind y z + ground pos x y, N2 = ground pos z + ground vel xyz
     RS_RESET_U0 = 8, RS_RESET_U1 = 9, RS_RESET_U2 = 10, RS_RESET_OBS_U = 11, RS_RESET_GPOS = 12, RS_RESET_GVEL = 13,
-    RS_DR0 = 14, RS_DR1 = 15, RS_DR2 = 16, RS_DR3 = 17
+    RS_DR0 = 14, RS_DR1 = 15, RS_DR2 = 16, RS_DR3 = 17,
+    // volley missile k = 1..3: evasion normals (stream RS_STEP_V1 + k - 1), spawn uniforms (RS_RESET_V1 + k - 1)
+    RS_STEP_V1 = 18, RS_RESET_V1 = 21
 };
 // physics_models.py:382-384 gust direction N(0,1)^3 and magnitude Exp(1)
 DEV void gust_draws(const Rng& rng, V3& g, float& e) {

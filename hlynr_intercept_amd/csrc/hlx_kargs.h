@@ -13,7 +13,7 @@ constexpr uint32_t KF_DYNAMIC = 1u << 31;
 constexpr uint32_t KF_CODEGEN_MASK = HLX_F_ATMOSPHERE | HLX_F_MACH_DRAG | HLX_F_ENH_WIND | HLX_F_THRUST_LAG |
                                      HLX_F_DOMAIN_RAND | HLX_F_VALIDATION | HLX_F_EVASION | HLX_F_PRECISION |
                                      HLX_F_PROX_FUZE | HLX_F_GROUND | HLX_F_SPHERICAL | HLX_F_TOWARD_MISSILE |
-                                     HLX_F_OBS_BODY | HLX_F_OBS_LOS;
+                                     HLX_F_OBS_BODY | HLX_F_OBS_LOS | HLX_F_VOLLEY;
 
 // State arena: 16-byte groups, blocked struct-of-arrays: arena[env / 64][group][env % 64].  Every load/store
 // of a group is one 16-byte-per-lane, 1-KiB-per-wave coalesced access, and a wave's whole state is one
@@ -33,7 +33,10 @@ enum : int {
     G_KFP,       // float4: covariance block p_pp, p_pv, p_vp, p_vv
     G_THRUST,    // float4: actual thrust xyz (thrust lag), pad               [thrust lag only]
     G_MISC,      // float4: T0, base_cd, transonic peak multiplier, pad       [domain randomisation only]
-    N_GROUPS
+    G_VPOS,      // float4 x HLX_MAX_VOLLEY: volley missile k position xyz, its minimum distance        [volley only]
+    G_VVEL = G_VPOS + HLX_MAX_VOLLEY,   // float4 x HLX_MAX_VOLLEY: velocity xyz, bits: 0 active | 8-9 priority index |
+                                        // 12-14 missiles intercepted (the last two in missile 0's word only)
+    N_GROUPS = G_VVEL + HLX_MAX_VOLLEY
 };
 // ground ring slot: double2 {rel_pos x, y}, {double rel_pos z, float quality, float sample-was-a-detection}, float4 {rel_vel xyz, pad}
 constexpr int GROUND_RING_WORDS16 = 3;
@@ -42,6 +45,7 @@ constexpr int GROUND_RING_WORDS16 = 3;
 struct KCfg {
     uint32_t flags;
     int32_t max_steps, g_delay, o_delay, o_cap;
+    int32_t volley_k;         // missiles per episode (volley mode), else 0
     float dt;                 // F(dt)
     double dt64, inv_dtf;     // dt ; 1 / (double)F(dt)
     float max_range, max_velocity, inv_max_range, inv_max_velocity;

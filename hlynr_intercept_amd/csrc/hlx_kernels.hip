@@ -196,6 +196,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
         // (five independent Philox chains in one straight-line block: instruction-level parallelism for
         // the lone wave of this SIMD, and it overlaps the state loads issued above)
         D3 z_ev = d3(0., 0., 0.), z_wind = z_ev, z_gp = z_ev, z_gv = z_ev;
+        D3 z_evk[HLX_MAX_VOLLEY - 1] = {z_ev, z_ev, z_ev};   // volley missiles 1..3 (generic instantiation only)
         float u_on = 0.f, u_g = 0.f;
         double u_dl = 0., u_gust = 1.;
         if (MODE == 0) {
@@ -221,6 +222,17 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 z_gp = d3((double)n6, (double)n7, (double)n8);
                 z_gv = d3((double)n9, (double)n10, (double)n11);
                 u_on = ua; u_g = ub; u_dl = (double)uc; u_gust = (double)ud;
+            }
+            if (HAS(HLX_F_VOLLEY)) {   // evasion draws of the other missiles of the volley
+#pragma unroll
+                for (int k = 1; k < HLX_MAX_VOLLEY; ++k) {
+                    if (noise_buf) z_evk[k - 1] = d3(SN[(20 + 3 * (k - 1)) * N], SN[(21 + 3 * (k - 1)) * N], SN[(22 + 3 * (k - 1)) * N]);
+                    else {
+                        float e0, e1, e2, e3;
+                        rng.normals4(RS_STEP_V1 + (uint32_t)(k - 1), e0, e1, e2, e3);
+                        z_evk[k - 1] = d3((double)e0, (double)e1, (double)e2);
+                    }
+                }
             }
         }
 
@@ -257,6 +269,24 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
         float T0 = g_misc.x;
         DragParams dp{c.subsonic, c.supersonic, c.mach_span, g_misc.z, g_misc.y, c.cd_super};
         if (HAS(HLX_F_DOMAIN_RAND)) dp.cd_super = (float)((double)dp.base_cd * c.super_mult);
+
+        // volley mode (environment.py:44): every missile of the volley; mpos / mvel above are `self.missile_state`,
+        // the entry `prio` of this list.  These groups always travel through the arena (also in the fused rollout).
+        V3 vp[HLX_MAX_VOLLEY], vv[HLX_MAX_VOLLEY];
+        float vmin[HLX_MAX_VOLLEY];
+        bool vact[HLX_MAX_VOLLEY];
+        int prio = 0, n_int = 0;
+        const int VK = HAS(HLX_F_VOLLEY) ? c.volley_k : 0;
+#pragma unroll
+        for (int k = 0; k < HLX_MAX_VOLLEY; ++k) {
+            vp[k] = v3(0.f, 0.f, 0.f); vv[k] = vp[k]; vmin[k] = 0.f; vact[k] = false;
+            if (HAS(HLX_F_VOLLEY)) {
+                const float4 a = A[(G_VPOS + k) * 64], b = A[(G_VVEL + k) * 64];
+                const uint32_t w = __float_as_uint(b.w);
+                vp[k] = v3(a.x, a.y, a.z); vmin[k] = a.w; vv[k] = v3(b.x, b.y, b.z); vact[k] = (w & 1u) != 0u;
+                if (k == 0) { prio = (int)((w >> 8) & 3u); n_int = (int)((w >> 12) & 7u); }
+            }
+        }
 
         float reward = 0.f, distance = 0.f;
         bool terminated = false, truncated = false, intercepted = false, hit_target = false, fuze = false,
@@ -343,7 +373,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
             }
             STAMP(4);   // interceptor integrated
             // -------------------------------------------------------------- missile (environment.py:1069-1117)
-            {
+            auto missile_step = [&](V3& mpos, V3& mvel, const D3& z_ev) {
                 float mrho = 1.225f, msos = 343.f;
                 if (HAS(HLX_F_ATMOSPHERE)) atmosphere(fmaxf(mpos.z, 0.f), T0, mrho, msos);
                 D3 sum;                                                             // drag + gravity, before evasion
@@ -375,7 +405,12 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 mvel = v3((float)((double)mvel.x + sum.x * c.dt64), (float)((double)mvel.y + sum.y * c.dt64),
                           (float)((double)mvel.z + sum.z * c.dt64));                // :1116
                 mpos = mpos + mvel * c.dt;                                          // :1117
-            }
+            };
+            if (HAS(HLX_F_VOLLEY)) {                                                // :631-636: every ACTIVE missile
+#pragma unroll
+                for (int k = 0; k < HLX_MAX_VOLLEY; ++k)
+                    if (k < VK && vact[k]) missile_step(vp[k], vv[k], k == 0 ? z_ev : z_evk[k > 0 ? k - 1 : 0]);
+            } else missile_step(mpos, mvel, z_ev);
             STAMP(5);   // missile integrated
             // -------------------------------------------------------------- wind (environment.py:1119-1129)
             if (HAS(HLX_F_ENH_WIND)) {                                              // physics_models.py:351-387
@@ -411,10 +446,42 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 };
                 wind = d3(upd(wind.x, c.base_wind[0], z.x), upd(wind.y, c.base_wind[1], z.y), upd(wind.z, c.base_wind[2], z.z));
             }
+            // -------------------------------------------------------------- volley: priority missile (:236-267, :643-650)
+            float vd[HLX_MAX_VOLLEY] = {0.f, 0.f, 0.f, 0.f};
+            if (HAS(HLX_F_VOLLEY)) {   // closest ACTIVE missile, the first wins ties, missile 0 when none is active
+                int sel = -1;
+                float best = 0.f;
+#pragma unroll
+                for (int k = 0; k < HLX_MAX_VOLLEY; ++k) {
+                    if (k < VK) {
+                        vd[k] = snorm3(vp[k] - ipos);
+                        if (vact[k] && (sel < 0 || vd[k] < best)) { sel = k; best = vd[k]; }
+                    }
+                }
+                prio = sel < 0 ? 0 : sel;
+                mpos = vp[0]; mvel = vv[0];
+#pragma unroll
+                for (int k = 1; k < HLX_MAX_VOLLEY; ++k) if (prio == k) { mpos = vp[k]; mvel = vv[k]; }
+            }
             // -------------------------------------------------------------- intercept / termination (:657-814)
             V3 rel = mpos - ipos;
             distance = snorm3(rel);
-            if (HAS(HLX_F_PROX_FUZE)) intercepted = distance < c.kill_radius;       // :700-703
+            if (HAS(HLX_F_VOLLEY)) {                                                // :661-692
+                const float thr = HAS(HLX_F_PROX_FUZE) ? c.kill_radius : hot.cur.radius;
+                intercepted = false;
+#pragma unroll
+                for (int k = 0; k < HLX_MAX_VOLLEY; ++k) {
+                    if (k < VK && vact[k]) {
+                        vmin[k] = (vd[k] < vmin[k]) ? vd[k] : vmin[k];
+                        if (vd[k] < thr) { intercepted = true; n_int += 1; vact[k] = false; }
+                    }
+                }
+                bool any = false;
+                distance = 0.f;                                                     // :691: 0.0 once nothing is left
+#pragma unroll
+                for (int k = 0; k < HLX_MAX_VOLLEY; ++k)
+                    if (k < VK && vact[k] && (!any || vd[k] < distance)) { distance = vd[k]; any = true; }
+            } else if (HAS(HLX_F_PROX_FUZE)) intercepted = distance < c.kill_radius; // :700-703
             else intercepted = distance < hot.cur.radius;
             min_distance = (distance < min_distance) ? distance : min_distance;     // :706
             if (intercepted) crossed = true;                                        // :709-710
@@ -422,7 +489,21 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
             const bool ground = mpos.z <= 0.f;
             const float gdx = mpos.x - c.target[0], gdy = mpos.y - c.target[1];
             const bool near_target = sqrtf((float)((double)(gdx * gdx) + (double)(gdy * gdy))) < 500.f;
-            if (HAS(HLX_F_PRECISION)) {                                             // :752-767
+            if (HAS(HLX_F_VOLLEY)) {                                                // :724-748
+                bool all_inactive = true;
+#pragma unroll
+                for (int k = 0; k < HLX_MAX_VOLLEY; ++k) {
+                    if (k < VK) {
+                        if (vp[k].z <= 0.f) {                                       // on the ground: neutralised
+                            vact[k] = false;
+                            const float gx = vp[k].x - c.target[0], gy = vp[k].y - c.target[1];
+                            if (sqrtf((float)((double)(gx * gx) + (double)(gy * gy))) < 500.f) hit_target = true;
+                        }
+                        if (vact[k]) all_inactive = false;
+                    }
+                }
+                if (all_inactive || fuze) terminated = true;
+            } else if (HAS(HLX_F_PRECISION)) {                                      // :752-767
                 if (ground) { terminated = true; hit_target = near_target; }
             } else {                                                                // :769-786
                 if (intercepted) terminated = true;
@@ -503,6 +584,15 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
             if (O->info.distance) O->info.distance[i] = distance;
             if (O->info.min_distance) O->info.min_distance[i] = min_distance;
             if (O->info.fuel) O->info.fuel[i] = fuel;
+            if (O->info.missiles) {                                                 // :846-847
+                int remaining = intercepted ? 0 : 1, got = intercepted ? 1 : 0;
+                if (HAS(HLX_F_VOLLEY)) {
+                    remaining = 0; got = n_int;
+#pragma unroll
+                    for (int k = 0; k < HLX_MAX_VOLLEY; ++k) remaining += (k < VK && vact[k]) ? 1 : 0;
+                }
+                O->info.missiles[i] = (uint8_t)(got | (remaining << 4));
+            }
         }
         // Kalman / ring registers become visible here (their loads were issued last, at kernel entry)
         PIN4(g_kfp); PIN2(g_kf0); PIN2(g_kf1); PIN2(g_kf2); PIN2(gr0); PIN4(gr1); PIN4(gr2);
@@ -553,21 +643,41 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                         u[8] = u01(x2.x); u[9] = u01(x2.y);
                     }
                     const V3 tp = v3(c.target[0], c.target[1], c.target[2]);
-                    if (HAS(HLX_F_SPHERICAL)) {                                     // :390-406
-                        const double PI = 3.141592653589793;
-                        double radius = k.mis_radius[0] + k.mis_radius[1] * u[0];
-                        double az = ((k.mis_az[0] + k.mis_az[1] * u[1]) * PI) / 180.0;
-                        double el = ((k.mis_el[0] + k.mis_el[1] * u[2]) * PI) / 180.0;
-                        mpos = v3((float)((double)tp.x + (radius * cos(el)) * cos(az)), (float)((double)tp.y + (radius * cos(el)) * sin(az)),
-                                  (float)((double)tp.z + radius * sin(el)));
-                    } else {                                                        // :409
-                        mpos = v3((float)(k.mis_lo[0] + k.mis_span[0] * u[0]), (float)(k.mis_lo[1] + k.mis_span[1] * u[1]),
-                                  (float)(k.mis_lo[2] + k.mis_span[2] * u[2]));
+                    auto spawn_missile = [&](double u0, double u1, double u2, double u3, V3& mpos, V3& mvel) {
+                        if (HAS(HLX_F_SPHERICAL)) {                                 // :390-406
+                            const double PI = 3.141592653589793;
+                            double radius = k.mis_radius[0] + k.mis_radius[1] * u0;
+                            double az = ((k.mis_az[0] + k.mis_az[1] * u1) * PI) / 180.0;
+                            double el = ((k.mis_el[0] + k.mis_el[1] * u2) * PI) / 180.0;
+                            mpos = v3((float)((double)tp.x + (radius * cos(el)) * cos(az)), (float)((double)tp.y + (radius * cos(el)) * sin(az)),
+                                      (float)((double)tp.z + radius * sin(el)));
+                        } else {                                                    // :409
+                            mpos = v3((float)(k.mis_lo[0] + k.mis_span[0] * u0), (float)(k.mis_lo[1] + k.mis_span[1] * u1),
+                                      (float)(k.mis_lo[2] + k.mis_span[2] * u2));
+                        }
+                        float speed = (float)(k.mis_speed[0] + k.mis_speed[1] * u3); // :415
+                        V3 tt = tp - mpos;
+                        float ttd = snorm3(tt);
+                        mvel = (ttd > 1e-6f) ? (tt / ttd) * speed : v3(0.f, 0.f, 0.f); // :418-423
+                    };
+                    spawn_missile(u[0], u[1], u[2], u[3], mpos, mvel);
+                    if (HAS(HLX_F_VOLLEY)) {                                        // :386-439: volley_size missiles, four draws each
+                        vp[0] = mpos; vv[0] = mvel;
+#pragma unroll
+                        for (int m = 1; m < HLX_MAX_VOLLEY; ++m) {
+                            if (m < VK) {
+                                double w0, w1, w2, w3;
+                                if (rbuf) {
+                                    const double* B = RN + (size_t)(32 + 4 * (m - 1)) * N;
+                                    w0 = B[0]; w1 = B[N]; w2 = B[2 * N]; w3 = B[3 * N];
+                                } else {
+                                    const uint4 x = rng.raw(RS_RESET_V1 + (uint32_t)(m - 1) + rsalt);
+                                    w0 = u01(x.x); w1 = u01(x.y); w2 = u01(x.z); w3 = u01(x.w);
+                                }
+                                spawn_missile(w0, w1, w2, w3, vp[m], vv[m]);
+                            }
+                        }
                     }
-                    float speed = (float)(k.mis_speed[0] + k.mis_speed[1] * u[3]);  // :415
-                    V3 tt = tp - mpos;
-                    float ttd = snorm3(tt);
-                    mvel = (ttd > 1e-6f) ? (tt / ttd) * speed : v3(0.f, 0.f, 0.f);  // :418-423
                     ipos = v3((float)(k.int_lo[0] + k.int_span[0] * u[4]), (float)(k.int_lo[1] + k.int_span[1] * u[5]),
                               (float)(k.int_lo[2] + k.int_span[2] * u[6]));         // :445
                     V3 rel0 = mpos - ipos;
@@ -577,9 +687,24 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                     else                                                            // :467
                         ivel = v3((float)(k.ivel_lo[0] + k.ivel_span[0] * u[7]), (float)(k.ivel_lo[1] + k.ivel_span[1] * u[8]),
                                   (float)(k.ivel_lo[2] + k.ivel_span[2] * u[9]));
+                    V3 orel = rel0;
+                    float oreld = reld;
+                    if (HAS(HLX_F_VOLLEY)) {   // per-missile minimum distances (:469-473); point at the CLOSEST missile (:476-487)
+                        float best = 0.f;
+#pragma unroll
+                        for (int m = 0; m < HLX_MAX_VOLLEY; ++m) {
+                            if (m < VK) {
+                                const V3 r = vp[m] - ipos;
+                                const float dm = snorm3(r);
+                                vmin[m] = dm; vact[m] = true;
+                                if (m == 0 || dm < best) { best = dm; orel = r; oreld = dm; }
+                            }
+                        }
+                        prio = 0; n_int = 0;                                        // :439 self.missile_state = missile_states[0]
+                    }
                     q = Quat{1.f, 0.f, 0.f, 0.f};                                   // :489-530 rotate +Z onto the LOS (float64)
-                    if (reld > 1e-6f) {
-                        V3 fd = rel0 / reld;
+                    if (oreld > 1e-6f) {
+                        V3 fd = orel / oreld;
                         double ax = -(double)fd.y, ay = (double)fd.x;
                         double axl = sqrt(ax * ax + ay * ay);
                         if (axl > 1e-6) {
@@ -916,6 +1041,16 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
             PUT2(G_KF2, g_kf2, make_double2(kxv.y, kxv.z));
             PUT4(G_KFP, g_kfp, make_float4(p_pp, p_pv, p_vp, p_vv));
             if (HAS(HLX_F_DOMAIN_RAND)) PUT4(G_MISC, g_misc, make_float4(T0, dp.base_cd, dp.peak, 0.f));
+            if (HAS(HLX_F_VOLLEY)) {
+#pragma unroll
+                for (int k = 0; k < HLX_MAX_VOLLEY; ++k) {
+                    if (k < VK) {
+                        const uint32_t w = (vact[k] ? 1u : 0u) | (k == 0 ? ((uint32_t)prio << 8) | ((uint32_t)n_int << 12) : 0u);
+                        STG(G_VPOS + k, make_float4(vp[k].x, vp[k].y, vp[k].z, vmin[k]));
+                        STG(G_VVEL + k, make_float4(vv[k].x, vv[k].y, vv[k].z, __uint_as_float(w)));
+                    }
+                }
+            }
 #undef PUT4
 #undef PUT2
             const uint32_t blk_bytes = (uint32_t)min(64, n - (int)blockIdx.x * 64) * 16u;   // partial tail block: clip

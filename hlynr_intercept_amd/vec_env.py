@@ -92,6 +92,9 @@ class LazyInfos(Sequence):
             "clamped": bool(flags & 8), "crossed_threshold": bool(flags & 16), "radar_detected": bool(flags & 32),
             "ground_radar_detected": bool(flags & 64),
             "TimeLimit.truncated": bool(h["truncated"][i] and not h["terminated"][i]),
+            # environment.py:844-847
+            "volley_mode": h["volley"][0], "volley_size": h["volley"][1],
+            "missiles_intercepted": int(h["missiles"][i]) & 15, "missiles_remaining": int(h["missiles"][i]) >> 4,
         }
         row = self._done.get(i)
         if row is not None:
@@ -140,10 +143,11 @@ class HlynrVecEnv:
         self.info = dict(distance=torch.zeros(n, device=dev), min_distance=torch.zeros(n, device=dev),
                          fuel=torch.zeros(n, device=dev), flags=torch.zeros(n, dtype=torch.uint8, device=dev),
                          episode_return=torch.zeros(n, device=dev),
-                         episode_length=torch.zeros(n, dtype=torch.int32, device=dev))
+                         episode_length=torch.zeros(n, dtype=torch.int32, device=dev),
+                         missiles=torch.zeros(n, dtype=torch.uint8, device=dev))
         self._info_soa = _lib.HlxInfoSoa(*(self.info[k].data_ptr() for k in
                                            ("distance", "min_distance", "fuel", "flags", "episode_return",
-                                            "episode_length")))
+                                            "episode_length", "missiles")))
         self._actions_dev = torch.zeros((n, _lib.ACT_DIM), dtype=torch.float32, device=dev)
         self._pending = None
         self._t_start = time.time()
@@ -253,7 +257,8 @@ class HlynrVecEnv:
         n_done = int(self.n_done.item())
         host = dict(terminated=term_h, truncated=trunc_h, distance=info["distance"].cpu().numpy(),
                     min_distance=info["min_distance"].cpu().numpy(), fuel=info["fuel"].cpu().numpy(),
-                    flags=info["flags"].cpu().numpy(), t_start=self._t_start)
+                    flags=info["flags"].cpu().numpy(), t_start=self._t_start, missiles=info["missiles"].cpu().numpy(),
+                    volley=(bool(self.rc.volley_mode), int(self.rc.volley_size) if self.rc.volley_mode else 1))
         done_rows: Dict[int, int] = {}
         if n_done:
             idx = self.done_idx[:n_done].to(self._torch.int64)
@@ -334,7 +339,7 @@ class HlynrVecEnv:
 
     # ------------------------------------------------------------------ parity / checkpoint hooks
     def set_noise(self, step_noise=None, reset_noise=None):
-        """Parity mode: slot-major float64 device tensors [20, N] / [32, N] replace the Philox draws (None restores)."""
+        """Parity mode: slot-major float64 device tensors [HLX_STEP_SLOTS, N] / [HLX_RESET_SLOTS, N] replace the Philox draws (None restores)."""
         for x in (step_noise, reset_noise):
             if x is not None and (x.dtype != self._torch.float64 or not x.is_contiguous()):
                 raise ValueError("noise tensors must be contiguous float64")
@@ -344,7 +349,7 @@ class HlynrVecEnv:
 
     def fill_noise(self, for_reset: bool = False):
         """The Philox draws of the next step (or, `for_reset=True`, of a reset issued now) as slot-major
-        tensors ([20, N], [32, N])."""
+        tensors ([HLX_STEP_SLOTS, N], [HLX_RESET_SLOTS, N])."""
         t = self._torch
         sn = t.zeros((_lib.STEP_SLOTS, self.num_envs), device=self.device, dtype=t.float64)
         rn = t.zeros((_lib.RESET_SLOTS, self.num_envs), device=self.device, dtype=t.float64)

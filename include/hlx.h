@@ -28,8 +28,9 @@ extern "C" {
 
 #define HLX_OBS_DIM 26      /* environment.py:192-194  Box(-2, 1, (26,), float32) */
 #define HLX_ACT_DIM 6       /* environment.py:195-197  Box(-1, 1, (6,), float32)  */
-#define HLX_STEP_SLOTS 20   /* unit random draws one step may consume */
-#define HLX_RESET_SLOTS 32  /* unit random draws one reset may consume */
+#define HLX_STEP_SLOTS 32   /* unit random draws one step may consume */
+#define HLX_RESET_SLOTS 48  /* unit random draws one reset may consume */
+#define HLX_MAX_VOLLEY 4    /* missiles per environment in volley mode (environment.py:42-44; inference.py:744 default 3) */
 #define HLX_MAX_DELAY 10    /* physics_randomizer.py:293 clamps the onboard delay to [1, 10] samples */
 #define HLX_RING_CAP (HLX_MAX_DELAY + 1)
 #define HLX_MAX_STEPS 8191  /* per-episode step counter is packed into 13 bits */
@@ -52,6 +53,9 @@ typedef enum hlx_status {
  *   3 missile speed U :415     4-6 interceptor position U :445     7-9 interceptor velocity U :467 (7 = speed U :461)
  *   10 onboard U  11 ground U  12-14 ground pos N  15-17 ground vel N  18 datalink U   (first observation, :570)
  *   19-31 domain-randomisation N x13 in draw order, physics_randomizer.py:165-214
+ * Volley mode, missile k = 1..3 (missile 0 uses the slots above): step slots 20+3(k-1) .. +2 evasion N (drawn only
+ * while that missile is active, environment.py:632-636); reset slots 32+4(k-1) .. +3 position U x3, speed U
+ * (environment.py:389-415, one set of four per missile in spawn order).
  */
 
 typedef enum hlx_flags {
@@ -70,7 +74,9 @@ typedef enum hlx_flags {
     HLX_F_OBS_BODY = 1u << 12,     /* observation_mode body_frame       core.py:870-876 */
     HLX_F_OBS_LOS = 1u << 13,      /* observation_mode los_frame + LOS action transform  core.py:791-868, environment.py:965-1063 */
     HLX_F_USE_CURRICULUM = 1u << 14, /* intercept-radius curriculum     environment.py:223-234 */
-    HLX_F_RADAR_CURRICULUM = 1u << 15 /* radar curriculum dict non-empty environment.py:274-351 */
+    HLX_F_RADAR_CURRICULUM = 1u << 15, /* radar curriculum dict non-empty environment.py:274-351 */
+    HLX_F_VOLLEY = 1u << 16        /* volley_mode: volley_size missiles per episode  environment.py:236-267, 386-439,
+                                      470-487, 631-692, 724-748 */
 } hlx_flags;
 
 /* Flat parameter set = the EFFECTIVE values the reference's constructor arrives at
@@ -98,6 +104,8 @@ typedef struct hlx_config {
     /* curriculum schedules, evaluated host-side by hlx_set_global_step */
     double initial_radius, final_radius, curriculum_steps;
     double rc_beam[4], rc_onboard[4], rc_ground[4], rc_noise[4]; /* {initial, final, start, end} */
+    int32_t volley_size;            /* 1..HLX_MAX_VOLLEY, read only with HLX_F_VOLLEY (environment.py:43) */
+    int32_t pad1;
 } hlx_config;
 
 /* Optional per-step side outputs (device pointers, each may be NULL = not wanted).
@@ -111,6 +119,8 @@ typedef struct hlx_info_soa {
                                      bit6 ground radar detected */
     float *episode_return;    /* [N] written only for envs that finished this step (Monitor 'r') */
     int32_t *episode_length;  /* [N] written only for envs that finished this step (Monitor 'l') */
+    uint8_t *missiles;        /* [N] low nibble info['missiles_intercepted'], high nibble info['missiles_remaining']
+                                     (environment.py:846-847) */
 } hlx_info_soa;
 
 /* Logical per-environment state, array-of-struct, HOST memory: parity injection and checkpointing. */
@@ -132,6 +142,12 @@ typedef struct hlx_env_state {
                                            sample-was-a-detection flag */
     float T0, base_cd, transonic_peak;  /* constants touched by domain randomisation */
     float ep_return;
+    /* volley mode: every missile of the volley; mis_pos / mis_vel above are the reference's `self.missile_state`,
+     * i.e. entry `prio` of this list (environment.py:643-650) */
+    float v_pos[HLX_MAX_VOLLEY][3], v_vel[HLX_MAX_VOLLEY][3];
+    float v_min[HLX_MAX_VOLLEY];        /* missile_min_distances */
+    int32_t v_active[HLX_MAX_VOLLEY];
+    int32_t prio, n_intercepted;
 } hlx_env_state;
 
 typedef struct hlx_env hlx_env;

@@ -114,8 +114,8 @@ def test_invariants_at_full_size():
     env.close()
 
 
-@pytest.mark.parametrize("physics,n", [("base", 1000), ("v2dr", 333), ("v2", 64)])
-def test_fused_rollout_is_bit_identical_to_single_step_launches(physics, n):
+@pytest.mark.parametrize("physics,n,volley", [("base", 1000, 0), ("v2dr", 333, 0), ("v2", 64, 0), ("base", 200, 3)])
+def test_fused_rollout_is_bit_identical_to_single_step_launches(physics, n, volley):
     """hlx_set_rollout_fused(k): k steps per launch with the state held in registers must reproduce the
     one-launch-per-step rollout bit for bit (same Philox keys, same arithmetic), including auto-resets
     (max_steps 40 forces several per env), a chunk size that does not divide T, a partial tail block and
@@ -123,6 +123,8 @@ def test_fused_rollout_is_bit_identical_to_single_step_launches(physics, n):
     import torch
     T, slots = 131, 7
     over = {"max_steps": 40}
+    if volley:   # generic kernel instantiation; the volley groups travel through the arena every step
+        over.update(volley_mode=True, volley_size=volley)
     ref, fus = _env(n, physics, over, seed=5), _env(n, physics, over, seed=5)
     g = torch.Generator(device=ref.device).manual_seed(1)
     tape = torch.rand((T, n, 6), generator=g, device=ref.device) * 2 - 1
