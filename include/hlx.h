@@ -12,7 +12,9 @@
  *    DEVICE pointer owned by the caller (e.g. a torch ROCm tensor's data_ptr); it must stay valid
  *    until the stream has passed the call.  `stream` is a hipStream_t (NULL = default stream).
  *  - the library owns the struct-of-arrays state arena (one hipMalloc at hlx_create); hlx_step
- *    allocates nothing and never synchronises, so it can be captured into a hipGraph.
+ *    allocates nothing and never synchronises.  (Not capturable into a replayed hipGraph as is: the vec-step
+ *    clock -- Philox counter and delay-ring phase -- is a kernel ARGUMENT that advances with every call, so a
+ *    replay would repeat one step's draws; for launch-bound small batches use hlx_set_rollout_fused instead.)
  *  - every function returns HLX_OK (0) or a negative hlx_status; hlx_last_error() gives the
  *    message (thread-local).  HIP errors are mapped, never abort().
  *  - one handle per device; a handle is not thread-safe, distinct handles are independent.

@@ -150,3 +150,27 @@ def test_fused_rollout_is_bit_identical_to_single_step_launches(physics, n, voll
     ra, rb = ref.step_torch(a), fus.step_torch(a)
     assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1])
     ref.close(); fus.close()
+
+
+def test_maximum_size_batch_steps_and_auto_resets():
+    """1 048 576 environments (16x BASELINE.json's per-GPU size, 16 384 workgroups): the arena / ring address
+    arithmetic in 64-bit, every lane live, auto-reset and the done list at scale."""
+    import torch
+    n = 1 << 20
+    env = _env(n, over={"max_steps": 3}, seed=2)
+    obs = env.reset_torch()
+    assert obs.shape == (n, 26) and torch.isfinite(obs).all()
+    g = torch.Generator(device=env.device).manual_seed(0)
+    for t in range(4):
+        a = torch.rand((n, 6), generator=g, device=env.device) * 2 - 1
+        obs, rew, term, trunc, info = env.step_torch(a, want_done_list=True)
+        assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+        n_done = int(info["n_done"].item())
+        assert n_done == int(((term | trunc) != 0).sum())
+        if t == 2:
+            assert n_done == n                                             # max_steps 3: every env truncates together
+            idx = info["done_idx"][:n_done].to(torch.int64)
+            assert int(torch.unique(idx).numel()) == n                     # each env listed exactly once
+    st = env.get_state()
+    assert st[n - 1].steps == 1 and st[0].steps == 1                       # all restarted, then stepped once
+    env.close()
