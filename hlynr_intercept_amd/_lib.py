@@ -71,7 +71,15 @@ class HlxObsConfig(C.Structure):   # include/hlx_obs.h hlx_obs_config
                 ("gamma", f64), ("epsilon", f64)]
 
 
-# every symbol include/hlx.h and include/hlx_obs.h declare: (restype, argtypes)
+class HlxHrlConfig(C.Structure):   # include/hlx_hrl.h hlx_hrl_config
+    _fields_ = [("n_envs", i32), ("obs_dim", i32), ("device", i32), ("decision_interval", i32), ("selector_mode", i32),
+                ("enable_forced", i32), ("enable_hysteresis", i32), ("enable_min_dwell", i32), ("default_option", i32),
+                ("min_dwell", i32 * 3), ("lock_min", f64), ("lock_search", f64), ("close_range", f64),
+                ("terminal_fuel_min", f64), ("miss_imminent", f64), ("fuel_critical", f64), ("h_lock_acquire", f64),
+                ("h_lock_maintain", f64), ("h_terminal_enter", f64), ("h_terminal_exit", f64)]
+
+
+# every symbol include/hlx.h, include/hlx_obs.h and include/hlx_hrl.h declare: (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
     "hlx_create": (C.c_int, [C.POINTER(HlxConfig), i32, i32, u64, i64, C.POINTER(_P)]),
@@ -106,6 +114,15 @@ SYMBOLS = {
     "hlx_obs_get_stats": (C.c_int, [_P, _P, _P, _P]),
     "hlx_obs_set_stats": (C.c_int, [_P, _P, _P, _P]),
     "hlx_obs_feature_dim": (i32, [_P]),
+    # include/hlx_hrl.h
+    "hlx_hrl_default_thresholds": (None, [C.POINTER(HlxHrlConfig)]),
+    "hlx_hrl_create": (C.c_int, [C.POINTER(HlxHrlConfig), C.POINTER(_P)]),
+    "hlx_hrl_destroy": (C.c_int, [_P]),
+    "hlx_hrl_reset": (C.c_int, [_P, _P, _P]),
+    "hlx_hrl_abstract": (C.c_int, [_P, _P, _P, _P]),
+    "hlx_hrl_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "hlx_hrl_get_state": (C.c_int, [_P, _P]),
+    "hlx_hrl_set_state": (C.c_int, [_P, _P]),
 }
 
 _lib = None

@@ -10,7 +10,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB = os.environ.get("HLX_LIBRARY") or os.path.join(_HERE, "libhlx.so")   # HLX_LIBRARY: diagnostic builds
 SOURCES = ["hlx_kernels.hip"]
 DEPS = ["hlx_kernels.hip", "hlx_host.inc", "hlx_obs.inc", "hlx_device.h", "hlx_kargs.h", os.path.join("..", "..", "include", "hlx.h"),
-        os.path.join("..", "..", "include", "hlx_obs.h")]
+        os.path.join("..", "..", "include", "hlx_obs.h"), "hlx_hrl.inc", os.path.join("..", "..", "include", "hlx_hrl.h")]
 
 
 def _hipcc() -> str:

@@ -1142,3 +1142,5 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
 #include "hlx_host.inc"
 // on-device VecFrameStack + VecNormalize behind the step (include/hlx_obs.h)
 #include "hlx_obs.inc"
+// on-device HRL controller logic (include/hlx_hrl.h)
+#include "hlx_hrl.inc"

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     out = set()
-    for header in ("hlx.h", "hlx_obs.h"):
+    for header in ("hlx.h", "hlx_obs.h", "hlx_hrl.h"):
         txt = open(os.path.join(ROOT, "include", header)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         out |= set(re.findall(r"\b(hlx_[a-z_0-9]+)\s*\(", txt))
@@ -56,6 +56,12 @@ def test_argument_validation_without_a_device():
     assert lib.hlx_obs_push(None, None, None, None, None, None, None, None, None) == -1
     assert lib.hlx_obs_destroy(None) == 0 and lib.hlx_obs_feature_dim(None) == 0
     assert C.sizeof(_lib.HlxObsConfig) == 64
+    # HRL controller (include/hlx_hrl.h)
+    hc = _lib.HlxHrlConfig(n_envs=8, obs_dim=27, device=0, decision_interval=100, selector_mode=1)
+    lib.hlx_hrl_default_thresholds(C.byref(hc))
+    assert hc.h_lock_acquire == 0.75 and list(hc.min_dwell) == [50, 50, 30] and hc.close_range == 200.0
+    assert lib.hlx_hrl_create(C.byref(hc), C.byref(p)) == -1 and b"obs_dim" in lib.hlx_last_error()
+    assert lib.hlx_hrl_step(None, None, None, None, None, None, None, None, None) == -1 and lib.hlx_hrl_destroy(None) == 0
 
 
 def test_config_struct_carries_the_flags():

@@ -1,0 +1,129 @@
+"""The on-device HRL controller (include/hlx_hrl.h, hlynr_intercept_amd/hrl.py) against (1) the golden vectors recorded
+from the reference's own manager and (2) the numpy restatement on random batches.  Discrete decisions and the clipped
+ratios of the abstract state: bit-exact."""
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+FIXTURES = sorted(glob.glob(os.path.join(HERE, "golden", "hrl", "*.npz")))
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+def test_gpu_controller_matches_reference_fixture(path):
+    import torch
+    from hlynr_intercept_amd.hrl import HRLController
+    from tests.test_hrl_oracle import stacked
+    fx = np.load(path)
+    stack = int(fx["stack"])
+    obs = stacked(fx["obs"], fx["did_reset"], stack)
+    n = 5    # the same sequence in five lanes
+    c = HRLController(n, obs_dim=26 * stack, decision_interval=int(fx["decision_interval"]),
+                      enable_forced_transitions=bool(fx["forced_enabled"]), enable_hysteresis=bool(fx["hysteresis"]),
+                      enable_min_dwell=bool(fx["min_dwell"]))
+    dev = c.device
+    obs_d = torch.tensor(obs, device=dev)
+    done = torch.tensor(fx["did_reset"].astype(np.uint8), device=dev)
+    zero = torch.zeros(n, dtype=torch.uint8, device=dev)
+    opts, infos, abstracts = [], [], []
+    for t in range(len(obs)):
+        prev = done[t - 1].expand(n).contiguous() if t > 0 else zero
+        o, a, i = c.step(obs_d[t].expand(n, -1).contiguous(), prev, zero)
+        opts.append(o.clone()); infos.append(i.clone()); abstracts.append(a.clone())
+    opts, infos, abstracts = torch.stack(opts).cpu().numpy(), torch.stack(infos).cpu().numpy(), torch.stack(abstracts).cpu().numpy()
+    assert np.all(opts == opts[:, :1]) and np.all(infos == infos[:, :1])
+    assert np.array_equal(opts[:, 0], fx["option"].astype(np.uint8))
+    assert np.array_equal(infos[:, 0] & 1, fx["switched"].astype(np.uint8))
+    assert np.array_equal((infos[:, 0] >> 1) & 3, fx["reason"].astype(np.uint8))
+    assert np.array_equal((infos[:, 0] >> 3) & 1, fx["forced"].astype(np.uint8))
+    assert np.array_equal((infos[:, 0] >> 5) & 3, fx["choice"].astype(np.uint8))
+    assert np.array_equal(abstracts[:, 0], fx["abstract"])                     # bit-exact float32
+    st = c.get_state()
+    assert st[0, 1] == fx["steps_in_option"][-1] and st[0, 3] == fx["total_steps"][-1]
+    c.close()
+
+
+@pytest.mark.parametrize("mode", ["rules", "external", "no_hysteresis"])
+def test_gpu_controller_matches_oracle_on_random_batches(mode):
+    import torch
+    from hlynr_intercept_amd.hrl import HRLController
+    from oracle.hrl_controller import Controller
+    n, T = 4099, 400
+    rng = np.random.default_rng(5)
+    kw = dict(decision_interval=13, enable_hysteresis=mode != "no_hysteresis")
+    ext = None
+    if mode == "external":     # a stand-in selector network: any function of the abstract state (out-of-range values get clamped)
+        ext = lambda a: (a[:, 2] * 4.0 - 0.5).floor().to(torch.int32)  # noqa: E731
+    g = HRLController(n, obs_dim=104, selector=ext if ext else "rules", **kw)
+    o = Controller(n, selector="rules", **kw)
+    lock = rng.random(n).astype(np.float32)
+    dist = rng.uniform(50, 600, n).astype(np.float32)
+    fuel = np.ones(n, np.float32)
+    done = np.zeros(n, bool)
+    for t in range(T):
+        lock = np.clip(lock + rng.normal(0, 0.05, n), 0, 1).astype(np.float32)
+        dist = np.clip(dist + rng.normal(-1, 12, n), 1, 900).astype(np.float32)
+        fuel = np.clip(fuel - rng.uniform(0, 0.006, n), 0, 1).astype(np.float32)
+        obs = rng.uniform(-2, 1, (n, 104)).astype(np.float32)
+        d = rng.standard_normal((n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        obs[:, 78:81] = (d * dist[:, None]).astype(np.float32)
+        obs[:, 78 + 12], obs[:, 78 + 14] = fuel, lock
+        obs[:, 78 + 13] = rng.uniform(-2, 14, n); obs[:, 78 + 15] = rng.normal(0, 400, n); obs[:, 78 + 16] = rng.uniform(-4, 4, n)
+        obs_d = torch.tensor(obs, device=g.device)
+        done_d = torch.tensor(done.astype(np.uint8), device=g.device)
+        choice = None
+        if ext:
+            from oracle.hrl_controller import abstract_observation
+            a, _ = abstract_observation(obs[:, -26:])
+            choice = np.floor(a[:, 2] * np.float32(4.0) - np.float32(0.5)).astype(np.int32)
+        opt, a_d, info = g.step(obs_d, done_d, None)
+        r = o.step(obs, done, choice)
+        assert np.array_equal(a_d.cpu().numpy(), r["abstract"]), t
+        assert np.array_equal(opt.cpu().numpy(), r["option"].astype(np.uint8)), t
+        ib = info.cpu().numpy()
+        assert np.array_equal(ib & 1, r["switched"].astype(np.uint8)) and np.array_equal((ib >> 1) & 3, r["reason"].astype(np.uint8))
+        assert np.array_equal((ib >> 4) & 1, r["due"].astype(np.uint8))
+        done = rng.random(n) < 0.01
+        fuel[done] = 1.0
+    st = g.get_state()
+    assert np.array_equal(st[:, 0], o.option) and np.array_equal(st[:, 1], o.steps_in_option)
+    assert np.array_equal(st[:, 2], o.om_steps) and np.array_equal(st[:, 3], o.total_steps)
+    assert len(np.unique(st[:, 0])) == 3                                        # all three options in use at the end
+    g.close()
+
+
+def test_select_actions_groups_specialists_by_option():
+    import torch
+    from hlynr_intercept_amd.hrl import HRLController, SEARCH, TRACK, TERMINAL
+    from hlynr_intercept_amd.scenarios import scenario_config
+    from hlynr_intercept_amd.vec_env import HlynrVecEnv
+    n = 512
+    env = HlynrVecEnv(scenario_config("medium", "base", {"max_steps": 60}), num_envs=n, seed=4)
+    ctl = HRLController(n, decision_interval=10)
+    calls = {SEARCH: 0, TRACK: 0, TERMINAL: 0}
+
+    def make(k, thrust):
+        def f(rows):
+            calls[k] += rows.shape[0]
+            a = torch.zeros((rows.shape[0], 6), device=rows.device)
+            a[:, 2] = thrust
+            return a
+        return f
+
+    spec = {SEARCH: make(SEARCH, 0.1), TRACK: make(TRACK, 0.5), TERMINAL: make(TERMINAL, 0.9)}
+    obs = env.reset_torch()
+    term = trunc = None
+    for t in range(80):
+        actions, option, info = ctl.select_actions(obs, spec, term, trunc)
+        want = torch.tensor([0.1, 0.5, 0.9], device=obs.device)[option.long()]
+        assert torch.equal(actions[:, 2], want)                                  # every env got ITS specialist's action
+        obs, rew, term, trunc, _ = env.step_torch(actions)
+    assert sum(calls.values()) == 80 * n and calls[TERMINAL] > 0                 # each env served by exactly one specialist per step
+    d = HRLController.decode_info(int(info[0]))
+    assert set(d) == {"hrl/option_switched", "hrl/switch_reason", "hrl/forced_transition", "hrl/selector_due", "hrl/selector_choice"}
+    env.close(); ctl.close()
