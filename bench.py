@@ -88,6 +88,10 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--physics", default="base", choices=["base", "v2dr"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for the barrier / max(time); gloo + --single-device rehearses the multi-rank "
+                         "path on a one-GPU box")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--fused", type=int, default=64,
                     help="also time the fused rollout (this many steps per launch, state held on-chip); 0 = skip")
     args = ap.parse_args()
@@ -103,12 +107,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the step is a HIP kernel; there is no CPU fallback)")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # RCCL; used only for barrier + max(time)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)   # nccl = RCCL; used only for barrier + max(time)
 
     from hlynr_intercept_amd.config import resolve_config
     from hlynr_intercept_amd.scenarios import scenario_config
@@ -144,7 +150,8 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms, launches = env.profile_read()
     env.profile(False)
-    elapsed = max_over_ranks(elapsed, dist, dev)
+    red_dev = dev if args.backend == "nccl" else None       # gloo reduces a host scalar
+    elapsed = max_over_ranks(elapsed, dist, red_dev)
     kern_us = 1e3 * kern_ms / max(1, launches)
     bytes_per_launch = BYTES_PER_ENV_STEP[args.physics] * n
     achieved = bytes_per_launch / (kern_us * 1e-6) / 1e9 if launches else 0.0
@@ -159,7 +166,7 @@ def main():
         t0 = time.perf_counter()
         env.rollout_torch(tape[:K], out_slots)
         sync_all()
-        f_elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
+        f_elapsed = max_over_ranks(time.perf_counter() - t0, dist, red_dev)
         f_ms, f_steps = env.profile_read()
         env.profile(False)
         env.set_rollout_fused(1)
