@@ -1,4 +1,5 @@
 set -e
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 300 --warmup 50 --no-cpu-baseline | tail -1 | cut -c1-400
-echo ---- 2 ranks, gloo, one device
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 2 --steps 300 --warmup 50 --backend gloo --single-device | tail -1 | cut -c1-600
+timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+for rep in 1 2 3; do for hw in 0 1; do
+HLX_HALF_WAVES=$hw python bench.py --steps 2000 --warmup 200 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('half=$hw us/step', round(d['ms_per_step']*1000,2), 'fused', round(d['fused_rollout']['ms_per_step']*1000,2))"
+done; done
