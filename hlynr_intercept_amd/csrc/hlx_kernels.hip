@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/hlx.h"
 #include "hlx_device.h"
 #include "hlx_kargs.h"
@@ -70,6 +72,24 @@ DEV void wt16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, double2 v)
     u32x4 d = {(uint32_t)__double2loint(v.x), (uint32_t)__double2hiint(v.x), (uint32_t)__double2loint(v.y), (uint32_t)__double2hiint(v.y)};
     __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, HLX_ST_AUX);
 }
+
+// Hot-parameter access: every lane holds two dwords of the 512-byte block (hotw0 = dword `lane`, hotw1 = dword
+// 64 + `lane`); a constant is fetched where it is used with one v_readlane per dword.  (Reading the whole block
+// into SGPRs once cost ~170 v_readlane plus ~200 v_writelane / v_readlane of SGPR spill traffic per wave.)
+template <typename T> struct HotRd;
+template <> struct HotRd<float> { static DEV float get(uint32_t w0, uint32_t w1, int off) {
+    return __uint_as_float(__builtin_amdgcn_readlane(off < 256 ? w0 : w1, (off >> 2) & 63)); } };
+template <> struct HotRd<int32_t> { static DEV int32_t get(uint32_t w0, uint32_t w1, int off) {
+    return (int32_t)__builtin_amdgcn_readlane(off < 256 ? w0 : w1, (off >> 2) & 63); } };
+template <> struct HotRd<uint32_t> { static DEV uint32_t get(uint32_t w0, uint32_t w1, int off) {
+    return __builtin_amdgcn_readlane(off < 256 ? w0 : w1, (off >> 2) & 63); } };
+template <> struct HotRd<double> { static DEV double get(uint32_t w0, uint32_t w1, int off) {
+    return __hiloint2double((int)HotRd<uint32_t>::get(w0, w1, off + 4), (int)HotRd<uint32_t>::get(w0, w1, off)); } };
+template <typename P> struct HotRd<P*> { static DEV P* get(uint32_t w0, uint32_t w1, int off) {
+    const unsigned long long lo = HotRd<uint32_t>::get(w0, w1, off), hi = HotRd<uint32_t>::get(w0, w1, off + 4);
+    return reinterpret_cast<P*>(lo | (hi << 32)); } };
+#define HOT(path) \
+    (HotRd<std::remove_cv_t<std::remove_reference_t<decltype(((const KHot*)nullptr)->path)>>>::get(hotw0, hotw1, (int)offsetof(KHot, path)))
 
 // NOISE = parity-mode instantiation that can take its random draws from caller-supplied float64 buffers;
 // the production instantiation (NOISE = false) contains no trace of that path.
@@ -139,16 +159,6 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
     // (Staging the block in LDS and letting every use be a broadcast ds_read was measured too: 190 fewer
     // instructions, 33 fewer VGPRs, but +0.65 us/step at 65 536 envs -- the lone wave of a SIMD eats each
     // ds_read's latency at the use site, while a v_readlane result is there after its issue cycles.)
-    KHot hot;
-    // hot parameter block -> uniform registers, one v_readlane per dword that is actually used
-#define BUILD_HOT()                                                                                                   \
-    do {                                                                                                              \
-        asm volatile("" : "+v"(hotw0), "+v"(hotw1));                                                                  \
-        uint32_t w_[sizeof(KHot) / 4];                                                                                \
-        _Pragma("unroll") for (int k_ = 0; k_ < (int)(sizeof(KHot) / 4); ++k_)                                        \
-            w_[k_] = __builtin_amdgcn_readlane(k_ < 64 ? hotw0 : hotw1, k_ & 63);                                     \
-        __builtin_memcpy(&hot, w_, sizeof(KHot));                                                                     \
-    } while (0)
     // per-step cursors (advance only in the fused rollout)
     unsigned long long t = t0;
     const float* actions = actions0;
@@ -159,7 +169,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
     int oslot = out_slot0;
     if (PERSIST) {   // the Kalman groups are loop-carried state too; constants once, before the loop
         g_kfp = A[G_KFP * 64]; g_kf0 = AD[G_KF0 * 64]; g_kf1 = AD[G_KF1 * 64]; g_kf2 = AD[G_KF2 * 64];
-        BUILD_HOT();
+        asm volatile("" : "+v"(hotw0), "+v"(hotw1));
         if (obs_out0) obs_out = obs_out0 + (size_t)oslot * n * HLX_OBS_DIM;
         reward_out = reward_out0 + (size_t)oslot * n; term_out = term_out0 + (size_t)oslot * n; trunc_out = trunc_out0 + (size_t)oslot * n;
     }
@@ -248,11 +258,9 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
         // (the Kalman / ring registers are released further down, right before the observation section)
         // the output pointers of the kernarg tail have landed by now
         asm volatile("" ::"s"(obs_out), "s"(reward_out), "s"(term_out), "s"(trunc_out));
-        if (!PERSIST) BUILD_HOT();
-        const KCfg& c = hot.c;
-        const KOpt* O = &hot.opt;
-        if (!HAS(HLX_F_DOMAIN_RAND)) g_misc.z = c.peak;
-        done_idx_out = O->done_idx;
+        if (!PERSIST) asm volatile("" : "+v"(hotw0), "+v"(hotw1));
+        if (!HAS(HLX_F_DOMAIN_RAND)) g_misc.z = HOT(c.peak);
+        done_idx_out = HOT(opt.done_idx);
         if (live) {   // ============================== per-environment work, live lanes only ==============================
         STAMP(2);   // Philox block done (loads still in flight)
         V3 ipos = v3(g_ipos.x, g_ipos.y, g_ipos.z), ivel = v3(g_ivel.x, g_ivel.y, g_ivel.z);
@@ -267,8 +275,8 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
         int on_delay = (int)(packed >> 28);
         V3 thrust_act = v3(g_thr.x, g_thr.y, g_thr.z);
         float T0 = g_misc.x;
-        DragParams dp{c.subsonic, c.supersonic, c.mach_span, g_misc.z, g_misc.y, c.cd_super};
-        if (HAS(HLX_F_DOMAIN_RAND)) dp.cd_super = (float)((double)dp.base_cd * c.super_mult);
+        DragParams dp{HOT(c.subsonic), HOT(c.supersonic), HOT(c.mach_span), g_misc.z, g_misc.y, HOT(c.cd_super)};
+        if (HAS(HLX_F_DOMAIN_RAND)) dp.cd_super = (float)((double)dp.base_cd * HOT(c.super_mult));
 
         // volley mode (environment.py:44): every missile of the volley; mpos / mvel above are `self.missile_state`,
         // the entry `prio` of this list.  These groups always travel through the arena (also in the fused rollout).
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
         float vmin[HLX_MAX_VOLLEY];
         bool vact[HLX_MAX_VOLLEY];
         int prio = 0, n_int = 0;
-        const int VK = HAS(HLX_F_VOLLEY) ? c.volley_k : 0;
+        const int VK = HAS(HLX_F_VOLLEY) ? HOT(c.volley_k) : 0;
 #pragma unroll
         for (int k = 0; k < HLX_MAX_VOLLEY; ++k) {
             vp[k] = v3(0.f, 0.f, 0.f); vv[k] = vp[k]; vmin[k] = 0.f; vact[k] = false;
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
 
             // Is the reference's wind a float64 array at this point?  Simple wind: float32 copy of
             // base_wind after reset, float64 from the first update on (environment.py:542,1127-1129).
-            const bool simple_wind = !HAS(HLX_F_ENH_WIND) && c.wind_var > 0.0;
+            const bool simple_wind = !HAS(HLX_F_ENH_WIND) && HOT(c.wind_var) > 0.0;
             const bool w64 = simple_wind && steps > 1;
 
             STAMP(3);   // first use of loaded state + clamp done
@@ -321,10 +329,10 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
             V3 thr = at * 10000.f, ang = aw * 20.f;                                 // :870-871
             if (HAS(HLX_F_THRUST_LAG)) {                                            // :874-878
                 V3 err = thr - thrust_act;
-                thrust_act = thrust_act + divc(err * c.dt, c.inv_tau);
+                thrust_act = thrust_act + divc(err * HOT(c.dt), HOT(c.inv_tau));
                 thr = thrust_act;
             }
-            float fc = (divc(snorm3(thr), 1.0 / 500.0) * 0.1f) * c.dt;              // :883-884
+            float fc = (divc(snorm3(thr), 1.0 / 500.0) * 0.1f) * HOT(c.dt);              // :883-884
             fuel = fuel - fc;
             if (fuel <= 0.f) { fuel = 0.f; thr = v3(0.f, 0.f, 0.f); thrust_act = thr; } // :888-892
             const V3 tacc = divc(thr, 1.0 / 500.0);                                 // :896
@@ -344,8 +352,8 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 }
                 D3 acc = d3((double)tacc.x + dacc.x, (double)tacc.y + dacc.y, ((double)tacc.z + dacc.z) + (double)GRAV); // :924
                 if (HAS(HLX_F_VALIDATION)) acc = nan_guard(acc, 50.0);
-                ivel = v3((float)((double)ivel.x + acc.x * c.dt64), (float)((double)ivel.y + acc.y * c.dt64),
-                          (float)((double)ivel.z + acc.z * c.dt64));                // :933
+                ivel = v3((float)((double)ivel.x + acc.x * HOT(c.dt64)), (float)((double)ivel.y + acc.y * HOT(c.dt64)),
+                          (float)((double)ivel.z + acc.z * HOT(c.dt64)));                // :933
             } else {
                 V3 va = ivel - to_v3(wind);
                 V3 dacc;
@@ -357,12 +365,12 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 }
                 V3 acc = v3(tacc.x + dacc.x, tacc.y + dacc.y, (tacc.z + dacc.z) + GRAV);
                 if (HAS(HLX_F_VALIDATION)) acc = to_v3(nan_guard(to_d3(acc), 50.0));
-                ivel = ivel + acc * c.dt;
+                ivel = ivel + acc * HOT(c.dt);
             }
-            ipos = ipos + ivel * c.dt;                                              // :934
+            ipos = ipos + ivel * HOT(c.dt);                                              // :934
             {
                 float wn = snorm3(ang);                                             // :940-956
-                float angle = wn * c.dt;
+                float angle = wn * HOT(c.dt);
                 if (angle > 1e-6f) {
                     float half = angle * 0.5f;                                      // angle / 2 (exact)
                     float ch = (float)cos_small((double)half), sh = (float)sin_small((double)half);
@@ -402,9 +410,9 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 if (HAS(HLX_F_EVASION))                                             // :1103-1108 (float64)
                     sum = d3(sum.x + z_ev.x * 2.0, sum.y + z_ev.y * 2.0, sum.z + z_ev.z * 2.0);
                 if (HAS(HLX_F_VALIDATION)) sum = nan_guard(sum, 20.0);
-                mvel = v3((float)((double)mvel.x + sum.x * c.dt64), (float)((double)mvel.y + sum.y * c.dt64),
-                          (float)((double)mvel.z + sum.z * c.dt64));                // :1116
-                mpos = mpos + mvel * c.dt;                                          // :1117
+                mvel = v3((float)((double)mvel.x + sum.x * HOT(c.dt64)), (float)((double)mvel.y + sum.y * HOT(c.dt64)),
+                          (float)((double)mvel.z + sum.z * HOT(c.dt64)));                // :1116
+                mpos = mpos + mvel * HOT(c.dt);                                          // :1117
             };
             if (HAS(HLX_F_VOLLEY)) {                                                // :631-636: every ACTIVE missile
 #pragma unroll
@@ -416,24 +424,24 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
             if (HAS(HLX_F_ENH_WIND)) {                                              // physics_models.py:351-387
                 float walt = fmaxf(ipos.z, 0.f);
                 float prof, ti;
-                if (walt <= 10.f) { prof = 1.0f; ti = c.ti_low; }
-                else if (walt <= c.bl_height) {
+                if (walt <= 10.f) { prof = 1.0f; ti = HOT(c.ti_low); }
+                else if (walt <= HOT(c.bl_height)) {
                     prof = powf(divc(walt, 1.0 / 10.0), 0.143f);                    // :319-324
-                    ti = c.ti_mid * (1.0f - (walt / c.bl_height) * 0.7f);           // :343-346
-                } else { prof = c.bl_prof; ti = c.ti_high; }
-                V3 w = v3(c.base_wind[0] * prof, c.base_wind[1] * prof, c.base_wind[2] * prof);
+                    ti = HOT(c.ti_mid) * (1.0f - (walt / HOT(c.bl_height)) * 0.7f);           // :343-346
+                } else { prof = HOT(c.bl_prof); ti = HOT(c.ti_high); }
+                V3 w = v3(HOT(c.base_wind[0]) * prof, HOT(c.base_wind[1]) * prof, HOT(c.base_wind[2]) * prof);
                 const D3 z = z_wind;
                 const double gu = u_gust;
                 if (ti > 0.f) {                                                     // :370-378
                     double scale = (double)(ti * snorm3(w));
-                    w = v3((float)((double)w.x + (scale * z.x) * c.turb_lp), (float)((double)w.y + (scale * z.y) * c.turb_lp),
-                           (float)((double)w.z + (scale * z.z) * c.turb_lp));
+                    w = v3((float)((double)w.x + (scale * z.x) * HOT(c.turb_lp)), (float)((double)w.y + (scale * z.y) * HOT(c.turb_lp)),
+                           (float)((double)w.z + (scale * z.z) * HOT(c.turb_lp)));
                 }
                 if (gu < 0.001) {                                                   // :381-385
                     D3 gd; double e;
                     if (noise_buf) { gd = d3(SN[7 * N], SN[8 * N], SN[9 * N]); e = SN[10 * N]; }
                     else { V3 g; float ef; gust_draws(rng, g, ef); gd = to_d3(g); e = (double)ef; }
-                    double gn = dnorm(gd) + 1e-6, gmag = c.gust_scale * e;
+                    double gn = dnorm(gd) + 1e-6, gmag = HOT(c.gust_scale) * e;
                     w = v3((float)((double)w.x + (gd.x / gn) * gmag), (float)((double)w.y + (gd.y / gn) * gmag),
                            (float)((double)w.z + (gd.z / gn) * gmag));
                 }
@@ -442,9 +450,9 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 const D3 z = z_wind;
                 auto upd = [&](double w, float base, double zz) {
                     double t1 = w64 ? 0.95 * w : (double)(0.95f * (float)w);
-                    return t1 + 0.05 * ((double)base + zz * c.wind_var);
+                    return t1 + 0.05 * ((double)base + zz * HOT(c.wind_var));
                 };
-                wind = d3(upd(wind.x, c.base_wind[0], z.x), upd(wind.y, c.base_wind[1], z.y), upd(wind.z, c.base_wind[2], z.z));
+                wind = d3(upd(wind.x, HOT(c.base_wind[0]), z.x), upd(wind.y, HOT(c.base_wind[1]), z.y), upd(wind.z, HOT(c.base_wind[2]), z.z));
             }
             // -------------------------------------------------------------- volley: priority missile (:236-267, :643-650)
             float vd[HLX_MAX_VOLLEY] = {0.f, 0.f, 0.f, 0.f};
@@ -467,7 +475,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
             V3 rel = mpos - ipos;
             distance = snorm3(rel);
             if (HAS(HLX_F_VOLLEY)) {                                                // :661-692
-                const float thr = HAS(HLX_F_PROX_FUZE) ? c.kill_radius : hot.cur.radius;
+                const float thr = HAS(HLX_F_PROX_FUZE) ? HOT(c.kill_radius) : HOT(cur.radius);
                 intercepted = false;
 #pragma unroll
                 for (int k = 0; k < HLX_MAX_VOLLEY; ++k) {
@@ -481,13 +489,13 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
 #pragma unroll
                 for (int k = 0; k < HLX_MAX_VOLLEY; ++k)
                     if (k < VK && vact[k] && (!any || vd[k] < distance)) { distance = vd[k]; any = true; }
-            } else if (HAS(HLX_F_PROX_FUZE)) intercepted = distance < c.kill_radius; // :700-703
-            else intercepted = distance < hot.cur.radius;
+            } else if (HAS(HLX_F_PROX_FUZE)) intercepted = distance < HOT(c.kill_radius); // :700-703
+            else intercepted = distance < HOT(cur.radius);
             min_distance = (distance < min_distance) ? distance : min_distance;     // :706
             if (intercepted) crossed = true;                                        // :709-710
-            if (HAS(HLX_F_PROX_FUZE) && min_distance < c.kill_radius) { fuze = true; intercepted = true; } // :715-717
+            if (HAS(HLX_F_PROX_FUZE) && min_distance < HOT(c.kill_radius)) { fuze = true; intercepted = true; } // :715-717
             const bool ground = mpos.z <= 0.f;
-            const float gdx = mpos.x - c.target[0], gdy = mpos.y - c.target[1];
+            const float gdx = mpos.x - HOT(c.target[0]), gdy = mpos.y - HOT(c.target[1]);
             const bool near_target = sqrtf((float)((double)(gdx * gdx) + (double)(gdy * gdy))) < 500.f;
             if (HAS(HLX_F_VOLLEY)) {                                                // :724-748
                 bool all_inactive = true;
@@ -496,7 +504,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                     if (k < VK) {
                         if (vp[k].z <= 0.f) {                                       // on the ground: neutralised
                             vact[k] = false;
-                            const float gx = vp[k].x - c.target[0], gy = vp[k].y - c.target[1];
+                            const float gx = vp[k].x - HOT(c.target[0]), gy = vp[k].y - HOT(c.target[1]);
                             if (sqrtf((float)((double)(gx * gx) + (double)(gy * gy))) < 500.f) hit_target = true;
                         }
                         if (vact[k]) all_inactive = false;
@@ -517,7 +525,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 last_distance = distance;
                 if (worsening > 500 && distance > 2500.f) terminated = true;
             }
-            truncated = steps >= c.max_steps;                                       // :813-814
+            truncated = steps >= HOT(c.max_steps);                                       // :813-814
             STAMP(6);   // wind + termination
             // -------------------------------------------------------------- reward (:1131-1320)
             if (HAS(HLX_F_PRECISION)) {
@@ -525,11 +533,11 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                     float md = min_distance;
                     if (crossed) {
                         reward = 3000.f;
-                        if (md < hot.cur.radius) reward = reward + ((hot.cur.radius - md) / hot.cur.radius) * 1000.f;
+                        if (md < HOT(cur.radius)) reward = reward + ((HOT(cur.radius) - md) / HOT(cur.radius)) * 1000.f;
                         reward = reward + expf(divc(-md, 1.0 / 25.0)) * 500.f;
                         reward = reward + expf(divc(-md, 1.0 / 10.0)) * 1000.f;
                         reward = reward + expf(divc(-md, 1.0 / 3.0)) * 500.f;
-                        reward = reward + (float)((double)(c.max_steps - steps) * 0.3);
+                        reward = reward + (float)((double)(HOT(c.max_steps) - steps) * 0.3);
                     } else {
                         reward = fmaxf(-md * 0.5f, -2000.f);
                         if (hit_target) reward -= 1000.f;
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                     }
                 } else {                                                            // :1203-1271
                     float delta = prev_distance - distance;
-                    float cv = divc(delta, c.inv_dtf);
+                    float cv = divc(delta, HOT(c.inv_dtf));
                     reward = clampf(divc(cv, 1.0 / 100.0), -0.5f, 2.0f) * 0.5f;
                     if (distance < 50.f) { reward = reward + delta * 5.f; reward = reward + expf(divc(-distance, 1.0 / 10.0)) * 1.0f; }
                     else if (distance < 150.f) reward = reward + delta * 3.f;
@@ -551,7 +559,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                     prev_distance = distance;
                 }
             } else if (intercepted) {                                               // :1274-1282
-                reward = (float)(5000.0 + (double)(c.max_steps - steps) * 0.5);
+                reward = (float)(5000.0 + (double)(HOT(c.max_steps) - steps) * 0.5);
             } else if (terminated) {                                                // :1284-1296
                 reward = fmaxf(-distance * 0.5f, -2000.f);
                 if (hit_target) reward -= 1000.f;
@@ -559,7 +567,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 else if (fuel <= 0.f) reward -= 300.f;
             } else {                                                                // :1298-1320
                 float delta = prev_distance - distance;
-                float cv = divc(delta, c.inv_dtf);
+                float cv = divc(delta, HOT(c.inv_dtf));
                 reward = clampf(divc(cv, 1.0 / 100.0), -0.5f, 2.0f) * 0.3f;
                 reward = reward + delta * ((distance < 200.f) ? 2.0f : (distance < 500.f) ? 1.0f : 0.5f);
                 reward = reward - 0.5f;
@@ -569,7 +577,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
             ep_return += reward;
         } else {
             // reset-only launch: `done` marks the envs to reset
-            done = O->reset_mask ? (O->reset_mask[i] != 0) : true;
+            done = HOT(opt.reset_mask) ? (HOT(opt.reset_mask)[i] != 0) : true;
         }
 
         STAMP(7);   // reward
@@ -581,17 +589,17 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
             reward_out[i] = reward;
             term_out[i] = terminated ? 1 : 0;
             trunc_out[i] = truncated ? 1 : 0;
-            if (O->info.distance) O->info.distance[i] = distance;
-            if (O->info.min_distance) O->info.min_distance[i] = min_distance;
-            if (O->info.fuel) O->info.fuel[i] = fuel;
-            if (O->info.missiles) {                                                 // :846-847
+            if (HOT(opt.info.distance)) HOT(opt.info.distance)[i] = distance;
+            if (HOT(opt.info.min_distance)) HOT(opt.info.min_distance)[i] = min_distance;
+            if (HOT(opt.info.fuel)) HOT(opt.info.fuel)[i] = fuel;
+            if (HOT(opt.info.missiles)) {                                                 // :846-847
                 int remaining = intercepted ? 0 : 1, got = intercepted ? 1 : 0;
                 if (HAS(HLX_F_VOLLEY)) {
                     remaining = 0; got = n_int;
 #pragma unroll
                     for (int k = 0; k < HLX_MAX_VOLLEY; ++k) remaining += (k < VK && vact[k]) ? 1 : 0;
                 }
-                O->info.missiles[i] = (uint8_t)(got | (remaining << 4));
+                HOT(opt.info.missiles)[i] = (uint8_t)(got | (remaining << 4));
             }
         }
         // Kalman / ring registers become visible here (their loads were issued last, at kernel entry)
@@ -603,7 +611,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
         // ---------------------------------------------------------------------- observation (+ auto-reset)
         // pass 0: observation of the stepped state.  pass 1 (only if some lane of the wave finished):
         // finished lanes respawn (environment.py:353-603) and build their first observation.
-        const int o_cap = c.o_cap;
+        const int o_cap = HOT(c.o_cap);
         float4 on_sample = make_float4(0.f, 0.f, 0.f, 0.f), g_s2 = on_sample;
         D3 g_sp = d3(0., 0., 0.);          // ground ring sample: float64 measured rel_pos, float32 quality/flag, rel_vel
         float g_sq = 0.f, g_sflag = 0.f;
@@ -621,13 +629,13 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 asm volatile("" : "+v"(rsalt));
                 if (done) {
                     if (MODE == 0) {
-                        if (O->terminal_obs) {
-                            float* to = O->terminal_obs + (size_t)i * HLX_OBS_DIM;
+                        if (HOT(opt.terminal_obs)) {
+                            float* to = HOT(opt.terminal_obs) + (size_t)i * HLX_OBS_DIM;
 #pragma unroll
                             for (int k = 0; k < HLX_OBS_DIM; ++k) to[k] = row[k];
                         }
-                        if (O->info.episode_return) O->info.episode_return[i] = ep_return;
-                        if (O->info.episode_length) O->info.episode_length[i] = steps;
+                        if (HOT(opt.info.episode_return)) HOT(opt.info.episode_return)[i] = ep_return;
+                        if (HOT(opt.info.episode_length)) HOT(opt.info.episode_length)[i] = steps;
                     }
                     // ---------------- spawn (environment.py:375-567): float64 draws cast to float32
                     const KCold& k = P->cold;
@@ -642,7 +650,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                         u[4] = u01(x1.x); u[5] = u01(x1.y); u[6] = u01(x1.z); u[7] = u01(x1.w);
                         u[8] = u01(x2.x); u[9] = u01(x2.y);
                     }
-                    const V3 tp = v3(c.target[0], c.target[1], c.target[2]);
+                    const V3 tp = v3(HOT(c.target[0]), HOT(c.target[1]), HOT(c.target[2]));
                     auto spawn_missile = [&](double u0, double u1, double u2, double u3, V3& mpos, V3& mvel) {
                         if (HAS(HLX_F_SPHERICAL)) {                                 // :390-406
                             const double PI = 3.141592653589793;
@@ -713,9 +721,9 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                             q = Quat{(float)cos(half), (float)((ax / axl) * sh), (float)((ay / axl) * sh), 0.f};
                         } else if (!(fd.z > 0.f)) q = Quat{0.f, 1.f, 0.f, 0.f};
                     }
-                    on_delay = c.o_delay;                                           // constructor value (core.py:292-293)
+                    on_delay = HOT(c.o_delay);                                           // constructor value (core.py:292-293)
                     fuel = 100.f;                                                   // :537
-                    wind = d3((double)c.base_wind[0], (double)c.base_wind[1], (double)c.base_wind[2]); // :542
+                    wind = d3((double)HOT(c.base_wind[0]), (double)HOT(c.base_wind[1]), (double)HOT(c.base_wind[2])); // :542
                     thrust_act = v3(0.f, 0.f, 0.f);                                 // :549
                     if (HAS(HLX_F_DOMAIN_RAND)) {                                   // :552-562, physics_randomizer.py
                         double zt, zd, zm, zs;
@@ -733,7 +741,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                             dp.base_cd = (float)(0.3 * mult(k.dr_var[2], zd));
                             dp.peak = (float)(3.0 * mult(k.dr_var[3], zm));
                         }
-                        if (c.o_delay > 0)                                          // :289-297
+                        if (HOT(c.o_delay) > 0)                                          // :289-297
                             on_delay = min(10, max(1, (int)(3.0 * mult(k.dr_var[4], zs))));
                     }
                     steps = 0; ep_return = 0.f;                                     // :565-566
@@ -765,23 +773,23 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 STAMP2(2);  // close-up: draws selected
                 const V3 rel = mpos - ipos;
                 const float range = snorm3(rel);
-                bool on_det = !(range > c.radar_range);                             // :539
+                bool on_det = !(range > HOT(c.radar_range));                             // :539
                 STAMP2(3);  // close-up: range
                 const V3 fwd = forward_vec(q);
                 STAMP2(4);  // close-up: forward vector
                 {   // :546-553  arccos(clip(fwd . to_missile)) > half_beam  <=>  clip(fwd . to_missile) < cos(half_beam)
                     const float cb = clampf(fdot(fwd, rel) * __builtin_amdgcn_rcpf(range + 1e-6f), -1.f, 1.f);
-                    if (cb < hot.cur.cos_half_beam) on_det = false;
+                    if (cb < HOT(cur.cos_half_beam)) on_det = false;
                 }
                 STAMP2(5);  // close-up: beam angle (acosf)
                 if (on_det) {                                                       // :559-566
-                    float aq = (c.radar_quality * (1.0f - (range * c.inv_radar_range) * 0.5f)) * hot.cur.on_rel;
+                    float aq = (HOT(c.radar_quality) * (1.0f - (range * HOT(c.inv_radar_range)) * 0.5f)) * HOT(cur.on_rel);
                     if (n_on > aq) on_det = false;
                 }
                 STAMP2(6);  // close-up: Bernoulli
                 V3 d_on = rel;
                 bool d_on_det = on_det;
-                if (c.o_delay > 0) {                                                // :576-588 onboard delay ring
+                if (HOT(c.o_delay) > 0) {                                                // :576-588 onboard delay ring
                     on_sample = make_float4(rel.x, rel.y, rel.z, on_det ? 1.f : 0.f);
                     d_on = v3(0.f, 0.f, 0.f); d_on_det = false;
                     if (pass == 0 && steps >= on_delay) {
@@ -797,28 +805,28 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 D3 g_pos = d3(0., 0., 0.);
                 V3 g_vel = v3(0.f, 0.f, 0.f);
                 float g_q = 0.f;
-                const V3 gp = v3(c.ground_pos[0], c.ground_pos[1], c.ground_pos[2]);
+                const V3 gp = v3(HOT(c.ground_pos[0]), HOT(c.ground_pos[1]), HOT(c.ground_pos[2]));
                 if (HAS(HLX_F_GROUND)) {
                     V3 g2m = mpos - gp;
                     float grange = fnorm(g2m);
-                    g_det = !(grange > c.g_max_range);                              // :396
+                    g_det = !(grange > HOT(c.g_max_range));                              // :396
                     if (g_det && grange > 1e-6f) {                                  // :401-406  asin is monotonic: compare sines
                         const float se = clampf(g2m.z * __builtin_amdgcn_rcpf(grange), -1.f, 1.f);
-                        if (se < c.sin_min_elev || se > c.sin_max_elev) g_det = false;
+                        if (se < HOT(c.sin_min_elev) || se > HOT(c.sin_max_elev)) g_det = false;
                     }
                     if (mpos.z < 50.f) g_det = false;                               // :409
                     if (g_det) {                                                    // :413-418
-                        float dpq = ((c.g_base_q * (1.0f - (grange * c.inv_g_max_range) * 0.4f)) * c.weather) * hot.cur.g_rel;
+                        float dpq = ((HOT(c.g_base_q) * (1.0f - (grange * HOT(c.inv_g_max_range)) * 0.4f)) * HOT(c.weather)) * HOT(cur.g_rel);
                         if (n_g > dpq) g_det = false;
                         else {
                             // :422-429 float64 measurement (kept float64 through the delay ring: the Kalman
                             // velocity estimate is tiny while detections are continuous, so outputs such as the
                             // lead-angle cosine are sensitive to 1e-4 m of measurement rounding)
-                            g_pos = d3((double)rel.x + c.g_range_acc * n_gp.x, (double)rel.y + c.g_range_acc * n_gp.y,
-                                       (double)rel.z + c.g_range_acc * n_gp.z);
+                            g_pos = d3((double)rel.x + HOT(c.g_range_acc) * n_gp.x, (double)rel.y + HOT(c.g_range_acc) * n_gp.y,
+                                       (double)rel.z + HOT(c.g_range_acc) * n_gp.z);
                             V3 rv = mvel - ivel;
-                            g_vel = v3((float)((double)rv.x + c.g_vel_acc * n_gv.x), (float)((double)rv.y + c.g_vel_acc * n_gv.y),
-                                       (float)((double)rv.z + c.g_vel_acc * n_gv.z));
+                            g_vel = v3((float)((double)rv.x + HOT(c.g_vel_acc) * n_gv.x), (float)((double)rv.y + HOT(c.g_vel_acc) * n_gv.y),
+                                       (float)((double)rv.z + HOT(c.g_vel_acc) * n_gv.z));
                             g_q = dpq;
                         }
                     }
@@ -827,11 +835,11 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 V3 d_gv = g_vel;
                 float d_gq = g_q;
                 bool d_g_det = g_det, d_g64 = g_det;    // d_g64: the delayed sample is a real (float64) measurement
-                if (HAS(HLX_F_GROUND) && c.g_delay > 0) {                           // :609-627 ground delay ring
+                if (HAS(HLX_F_GROUND) && HOT(c.g_delay) > 0) {                           // :609-627 ground delay ring
                     g_sp = g_pos; g_sq = g_q; g_sflag = g_det ? 1.f : 0.f;
                     g_s2 = make_float4(g_vel.x, g_vel.y, g_vel.z, 0.f);
                     d_gp64 = d3(0., 0., 0.); d_gv = v3(0.f, 0.f, 0.f); d_gq = 0.f; d_g_det = false; d_g64 = false;
-                    if (pass == 0 && steps >= c.g_delay) {                          // sample pre-loaded at kernel entry
+                    if (pass == 0 && steps >= HOT(c.g_delay)) {                          // sample pre-loaded at kernel entry
                         const double2 s0 = gr0;
                         const float4 s1 = gr1, s2 = gr2;
                         d_gp64 = d3(s0.x, s0.y, __hiloint2double(__float_as_int(s1.y), __float_as_int(s1.x)));
@@ -845,8 +853,8 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 float datalink = 0.f;
                 if (HAS(HLX_F_GROUND)) {
                     float lr = fnorm(ipos - gp);
-                    if (!(lr > c.max_datalink) && !(n_dl < c.packet_loss)) {
-                        float x = lr * c.inv_max_datalink;
+                    if (!(lr > HOT(c.max_datalink)) && !(n_dl < HOT(c.packet_loss))) {
+                        float x = lr * HOT(c.inv_max_datalink);
                         float vr = fnorm(ivel) * 0.001f;
                         float dop = (0.3f < vr) ? (float)(1.0 - 0.3) : (1.0f - vr);
                         datalink = clampf(((1.0f - x * x) * dop) * 0.95f, 0.f, 1.f);
@@ -855,11 +863,11 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                 // ---- fusion confidence (core.py:476-509) - pure output
                 float fusion;
                 if (!d_on_det && !d_g_det) fusion = 0.f;
-                else if (!d_g_det) fusion = (float)(c.radar_quality64 * 0.5);
+                else if (!d_g_det) fusion = (float)(HOT(c.radar_quality64) * 0.5);
                 else if (!d_on_det) fusion = d_gq * 0.6f;
                 else {
                     float agree = 1.0f - fminf(fnorm(d_on - d_gp) * 0.005f, 1.0f);
-                    fusion = clampf((float)(0.35 * c.radar_quality64) + 0.50f * d_gq + 0.15f * agree, 0.f, 1.f);
+                    fusion = clampf((float)(0.35 * HOT(c.radar_quality64)) + 0.50f * d_gq + 0.15f * agree, 0.f, 1.f);
                 }
                 if (pass == 0) det_bits = (d_on_det ? 32u : 0u) | (d_g_det ? 64u : 0u);
 
@@ -874,14 +882,14 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                     if (d_on_det && d_g_det) {
                         m64 = d_g64;
                         if (m64) {
-                            const double itot = 1.0 / (double)(c.radar_quality + d_gq);   // one float64 reciprocal for 3 quotients
-                            z = d3(((double)(d_on.x * c.radar_quality) + d_gp64.x * (double)d_gq) * itot,
-                                   ((double)(d_on.y * c.radar_quality) + d_gp64.y * (double)d_gq) * itot,
-                                   ((double)(d_on.z * c.radar_quality) + d_gp64.z * (double)d_gq) * itot);
+                            const double itot = 1.0 / (double)(HOT(c.radar_quality) + d_gq);   // one float64 reciprocal for 3 quotients
+                            z = d3(((double)(d_on.x * HOT(c.radar_quality)) + d_gp64.x * (double)d_gq) * itot,
+                                   ((double)(d_on.y * HOT(c.radar_quality)) + d_gp64.y * (double)d_gq) * itot,
+                                   ((double)(d_on.z * HOT(c.radar_quality)) + d_gp64.z * (double)d_gq) * itot);
                         } else {   // stale zero sample: weight 0.0 (python float) -> float32 arithmetic
-                            float total = (float)c.radar_quality64;
-                            z = to_d3(v3((d_on.x * c.radar_quality) / total, (d_on.y * c.radar_quality) / total,
-                                         (d_on.z * c.radar_quality) / total));
+                            float total = (float)HOT(c.radar_quality64);
+                            z = to_d3(v3((d_on.x * HOT(c.radar_quality)) / total, (d_on.y * HOT(c.radar_quality)) / total,
+                                         (d_on.z * HOT(c.radar_quality)) / total));
                         }
                     } else if (d_on_det) { m64 = false; z = to_d3(d_on); }
                     else { m64 = d_g64; z = d_gp64; }
@@ -908,18 +916,18 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                     have_track = true;
                 } else {                                                            // :760-774
                     if (kf_init) {                                                  // core.py:80-89 predict
-                        const double dtf = (double)c.dt;
+                        const double dtf = (double)HOT(c.dt);
                         kxp = d3(rr(kxp.x + rr(dtf * kxv.x, kf_x64), kf_x64), rr(kxp.y + rr(dtf * kxv.y, kf_x64), kf_x64),
                                  rr(kxp.z + rr(dtf * kxv.z, kf_x64), kf_x64));
-                        const float a_pp = p_pp + c.dt * p_vp, a_pv = p_pv + c.dt * p_vv;
-                        const float n_pp = a_pp + a_pv * c.dt, n_vp = p_vp + p_vv * c.dt;
-                        p_pp = n_pp + c.q11; p_pv = a_pv + c.q12; p_vp = n_vp + c.q12; p_vv = p_vv + c.q22;
+                        const float a_pp = p_pp + HOT(c.dt) * p_vp, a_pv = p_pv + HOT(c.dt) * p_vv;
+                        const float n_pp = a_pp + a_pv * HOT(c.dt), n_vp = p_vp + p_vv * HOT(c.dt);
+                        p_pp = n_pp + HOT(c.q11); p_pv = a_pv + HOT(c.q12); p_vp = n_vp + HOT(c.q12); p_vv = p_vv + HOT(c.q22);
                     }
                     have_track = kf_init;
                 }
                 STAMP(11);  // measurement fusion + Kalman filter
                 // ---- observation vector: pure outputs, ordinary fast float32 from here on
-                const float inv_mr = c.inv_max_range, inv_mv = c.inv_max_velocity;
+                const float inv_mr = HOT(c.inv_max_range), inv_mv = HOT(c.inv_max_velocity);
                 if (have_track) {                                                   // :778-906
                     // filtered relative position / velocity in the Kalman state's dtype (:758-759,:767-768); the
                     // target-velocity estimate frv + ivel (:861) cancels back to the (small) Kalman velocity, so it
@@ -962,7 +970,7 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
                     }
                     row[13] = (closing > 0.f) ? clampf(1.0f - fdiv(rrange, closing) * 0.01f, -1.f, 1.f) : -1.f; // :885-889
                     float tq = clampf(1.0f - ((p_pp + p_pp) + p_pp) * 1e-4f, 0.f, 1.f); // :892-893 trace of 3 equal blocks
-                    if (d_on_det) tq *= c.radar_quality;                            // :894-895
+                    if (d_on_det) tq *= HOT(c.radar_quality);                            // :894-895
                     row[14] = tq;
                     row[15] = clampf(closing * inv_mv, -1.f, 1.f);                  // :899
                     row[16] = (rrange > 1e-6f) ? fdiv(fdot(fwd, frp), rrange) : 1.0f; // :902-906
@@ -1054,12 +1062,12 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
 #undef PUT4
 #undef PUT2
             const uint32_t blk_bytes = (uint32_t)min(64, n - (int)blockIdx.x * 64) * 16u;   // partial tail block: clip
-            if (c.o_delay > 0) {
+            if (HOT(c.o_delay) > 0) {
                 const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
                     oring + (size_t)o_wslot * N + (size_t)blockIdx.x * 64, 0, blk_bytes, 0x00020000);
                 wt16(rsO, lane16, 0u, on_sample);
             }
-            if (HAS(HLX_F_GROUND) && c.g_delay > 0) {
+            if (HAS(HLX_F_GROUND) && HOT(c.g_delay) > 0) {
                 // the slot's three planes are N words apart: one descriptor per plane keeps every offset 32-bit at any N
                 float4* R = gring + ((size_t)g_wslot * GROUND_RING_WORDS16) * N + (size_t)blockIdx.x * 64;
                 wt16(__builtin_amdgcn_make_buffer_rsrc(R, 0, blk_bytes, 0x00020000), lane16, 0u, make_double2(g_sp.x, g_sp.y));
@@ -1069,8 +1077,8 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
             }
         }
         if (MODE == 0) {
-            if (O->info.flags)
-                O->info.flags[i] = (uint8_t)((intercepted ? 1u : 0u) | (hit_target ? 2u : 0u) | (fuze ? 4u : 0u) |
+            if (HOT(opt.info.flags))
+                HOT(opt.info.flags)[i] = (uint8_t)((intercepted ? 1u : 0u) | (hit_target ? 2u : 0u) | (fuze ? 4u : 0u) |
                                             (clamped ? 8u : 0u) | (crossed ? 16u : 0u) | det_bits);
         }
         }   // if (live)
@@ -1126,7 +1134,6 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
         __syncthreads();   // the tile is rewritten by the next step
     }
     }   // step loop
-#undef BUILD_HOT
     if (PERSIST && live) {   // state back to the arena, once
         STG(G_IPOS, g_ipos); STG(G_IVEL, g_ivel); STG(G_QUAT, g_quat); STG(G_MPOS, g_mpos); STG(G_MVEL, g_mvel);
         STG(G_W0, g_w0); STG(G_W1, g_w1);
