@@ -97,7 +97,10 @@ template <typename P> struct HotRd<P*> { static DEV P* get(uint32_t w0, uint32_t
 // over `T` consecutive steps -- state groups are read before the first and written after the last step; per
 // step only the action row and the delayed ring sample come in and observation/reward/flags/ring sample go out.
 // Same arithmetic, same Philox keys (clock t + k), hence bit-identical to T single-step launches.
-template <uint32_t SPEC, int MODE /*0 = step, 1 = reset-only*/, bool NOISE, bool PERSIST = false>
+// LATE = instantiation for small batches (<= two 64-env waves per SIMD): the Kalman groups and the delayed ring sample are
+// loaded as a second batch after the Philox block instead of at kernel entry (see below; a run-time switch was tried
+// and lost both ways -- the optimiser merges the two load sites).
+template <uint32_t SPEC, int MODE /*0 = step, 1 = reset-only*/, bool NOISE, bool PERSIST = false, bool LATE = false>
 __global__ __launch_bounds__(64) void hlx_env_kernel(
     // ---- 14 dwords preloaded into SGPRs by the dispatcher: everything needed to issue the state, action and
     //      ring loads and to run the Philox block without waiting for memory
@@ -140,10 +143,9 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
         __builtin_amdgcn_make_buffer_rsrc(arena + (size_t)blockIdx.x * (N_GROUPS * 64), 0, N_GROUPS * 64 * 16, 0x00020000);
     const uint32_t lane16 = (uint32_t)lane * 16u;
 #define STG(G, v) wt16(rsA, lane16, (uint32_t)(G) * 1024u, (v))
-    // ------------------------------------------------------------------ issue every load up front
-    // (state groups, action row, the delayed ground-ring sample whose slot depends only on the global
-    // clock); the Philox draws below do not depend on them and run while the loads are in flight.
-    // issue order = order of need: the integrator's groups first, the Kalman filter's (needed ~5k cycles later) last
+    // ------------------------------------------------------------------ first load batch, issued at entry
+    // (the integrator's state groups and the action row); the Philox draws below do not depend on them and run
+    // while the loads are in flight.  The Kalman groups and the ring sample follow as a second batch after Philox.
     float4 g_ipos = A[G_IPOS * 64], g_ivel = A[G_IVEL * 64], g_quat = A[G_QUAT * 64], g_mpos = A[G_MPOS * 64];
     float4 g_mvel = A[G_MVEL * 64], g_w1 = A[G_W1 * 64];
     double2 g_w0 = AD[G_W0 * 64];
@@ -186,13 +188,17 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
         if (MODE == 0) {
             const float2* ap = reinterpret_cast<const float2*>(actions + (size_t)ic * HLX_ACT_DIM);
             a01 = ap[0]; a23 = ap[1]; a45 = ap[2];
-            if (HAS(HLX_F_GROUND)) {   // unconditional when the station exists (the host always allocates >= 1 slot):
-                                       // a runtime guard here would put a register merge, i.e. a wait, in front of Philox
+        }
+        // Kalman groups + delayed ground-ring sample: with the rest at entry when the batch is large (several waves per
+        // SIMD: more loads in flight = more HBM bandwidth), as a second batch after Philox when it is small (below)
+        constexpr bool late_loads = LATE;    // instantiation chosen by the host from the batch size
+        if (!late_loads) {
+            if (MODE == 0 && HAS(HLX_F_GROUND)) {   // unconditional when the station exists (the host always allocates >= 1 slot)
                 const float4* R = gring + ((size_t)g_rslot * GROUND_RING_WORDS16) * N + ic;   // slot (t - g_delay) mod cap
                 gr0 = *reinterpret_cast<const double2*>(R); gr1 = R[N]; gr2 = R[2 * N];
             }
+            if (!PERSIST) { g_kfp = A[G_KFP * 64]; g_kf0 = AD[G_KF0 * 64]; g_kf1 = AD[G_KF1 * 64]; g_kf2 = AD[G_KF2 * 64]; }
         }
-        if (!PERSIST) { g_kfp = A[G_KFP * 64]; g_kf0 = AD[G_KF0 * 64]; g_kf1 = AD[G_KF1 * 64]; g_kf2 = AD[G_KF2 * 64]; }
 
         STAMP(1);   // all loads issued
         const bool noise_buf = NOISE && P->hot.opt.step_noise != nullptr;    // parity instantiation only
@@ -251,6 +257,20 @@ __global__ __launch_bounds__(64) void hlx_env_kernel(
         // cold-start latency BEFORE doing the one piece of work that needs no memory.
 #define PIN4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
 #define PIN2(v) asm volatile("" : "+v"((v).x), "+v"((v).y))
+        if (late_loads) {
+            // Second load batch: the Kalman groups and the delayed ground-ring sample are first needed ~5k cycles from
+            // here.  At one wave per SIMD the load phase is bandwidth-bound and exposed: issued at kernel entry with
+            // everything else they share the cold-start bandwidth with the integrator's groups (the whole chip asks
+            // for 15.7 MB in the same microsecond) and delay the physics (+0.55 us at 65 536 envs); issued here they
+            // move while the physics runs.  `late` is an opaque zero that pins them below Philox.
+            uint32_t late = 0;
+            asm volatile("" : "+v"(late));
+            if (MODE == 0 && HAS(HLX_F_GROUND)) {   // unconditional when the station exists (the host always allocates >= 1 slot)
+                const float4* R = gring + ((size_t)g_rslot * GROUND_RING_WORDS16) * N + ic + late;   // slot (t - g_delay) mod cap
+                gr0 = *reinterpret_cast<const double2*>(R); gr1 = R[N]; gr2 = R[2 * N];
+            }
+            if (!PERSIST) { g_kfp = A[G_KFP * 64 + late]; g_kf0 = AD[G_KF0 * 64 + late]; g_kf1 = AD[G_KF1 * 64 + late]; g_kf2 = AD[G_KF2 * 64 + late]; }
+        }
         PIN4(g_ipos); PIN4(g_ivel); PIN4(g_quat); PIN4(g_mpos); PIN4(g_mvel); PIN4(g_w1); PIN2(g_w0);
         if (HAS(HLX_F_THRUST_LAG)) PIN4(g_thr);
         if (HAS(HLX_F_DOMAIN_RAND)) PIN4(g_misc);
