@@ -1,6 +1,6 @@
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
-key = sys.argv[2] if len(sys.argv) > 2 else "hlx_env_kernel<608u, 0, false, false>"
+key = sys.argv[2] if len(sys.argv) > 2 else "hlx_env_kernel<608u, 0, false, false"
 acc = collections.defaultdict(list)
 for r in rows:
     if key in r["Kernel_Name"]:
