@@ -101,7 +101,10 @@ template <typename P> struct HotRd<P*> { static DEV P* get(uint32_t w0, uint32_t
 // loaded as a second batch after the Philox block instead of at kernel entry (see below; a run-time switch was tried
 // and lost both ways -- the optimiser merges the two load sites).
 template <uint32_t SPEC, int MODE /*0 = step, 1 = reset-only*/, bool NOISE, bool PERSIST = false, bool LATE = false>
-__global__ __launch_bounds__(64) void hlx_env_kernel(
+// waves_per_eu(2): keep every instantiation within 256 VGPRs so that two waves fit on a SIMD.  The single-step kernels
+// are there anyway (183); the fused-rollout ones spill 4-19 dwords to scratch for it and run 1.5x faster once the batch
+// gives a SIMD two waves (1 M envs: 107 -> 72 us per step, 1.46e10 env-steps/s), unchanged below that.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hlx_env_kernel(
     // ---- 14 dwords preloaded into SGPRs by the dispatcher: everything needed to issue the state, action and
     //      ring loads and to run the Philox block without waiting for memory
     float4* __restrict__ arena, const KParams* __restrict__ P, const float* __restrict__ actions0,
