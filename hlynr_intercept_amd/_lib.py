@@ -138,12 +138,20 @@ def load(build_if_missing: bool = True):
     if _lib is not None:
         return _lib
     path = _build.LIB
-    if build_if_missing and _build.needs_build():
-        try:
-            _build.build()
-        except Exception as exc:  # pragma: no cover
-            if not os.path.exists(path):
+    if build_if_missing and not os.path.exists(path) and not os.environ.get("HLX_LIBRARY"):
+        # Built in-tree by `__graft_entry__.build()` / `python -m hlynr_intercept_amd.build`.  If it is absent, one
+        # process per node builds it (local rank 0) and the others wait: N ranks compiling into the same file would race.
+        if os.environ.get("LOCAL_RANK", "0") == "0":
+            try:
+                _build.build(force=True)
+            except Exception as exc:  # pragma: no cover
                 raise RuntimeError(f"libhlx.so is missing and could not be built: {exc}") from exc
+        else:  # pragma: no cover
+            import time
+            for _ in range(600):
+                if os.path.exists(path):
+                    break
+                time.sleep(0.5)
     if not os.path.exists(path):
         raise RuntimeError(f"HIP library not found at {path}: build it with `python -m hlynr_intercept_amd.build`")
     try:
