@@ -92,6 +92,9 @@ def main():
                     help="process-group backend for the barrier / max(time); gloo + --single-device rehearses the multi-rank "
                          "path on a one-GPU box")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--no-extra-points", action="store_true",
+                    help="skip BASELINE config 3 (v2dr physics, 65 536 envs) and the 4 M-env cache-defeating point of "
+                         "SURVEY.md 8(d) that a single-GPU run also times (~10 s)")
     ap.add_argument("--fused", type=int, default=64,
                     help="also time the fused rollout (this many steps per launch, state held on-chip); 0 = skip")
     args = ap.parse_args()
@@ -175,6 +178,29 @@ def main():
                  "note": "same K steps through hlx_rollout with hlx_set_rollout_fused: state stays in registers for "
                          "steps_per_launch steps, bit-identical results; not the headline (a policy in the loop needs one launch per step)"}
 
+    # config 3 and a batch whose state (2.6 GB) defeats the 256 MB Infinity Cache, same clocking method
+    extra = None
+    if not args.no_extra_points and world == 1:
+        extra = []
+        env.close()
+        for phys, n_x, k_x in (("v2dr", ENVS_PER_GPU, 1000), ("base", 4 * 1024 * 1024, 60)):
+            rc_x = resolve_config(scenario_config("medium", phys))
+            env = HlynrVecEnv(resolved=rc_x, num_envs=n_x, device=local_rank, seed=1000)
+            tape_x = torch.rand((k_x, n_x, 6), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
+            env.reset_torch()
+            env.rollout_torch(tape_x[:max(1, k_x // 4)], out_slots)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            env.rollout_torch(tape_x, out_slots)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            b = BYTES_PER_ENV_STEP[phys]
+            extra.append({"workload": f"medium scenario, {phys} physics, {n_x} envs/GPU", "value": n_x * k_x / dt, "unit": "env-steps/s",
+                          "us_per_step": 1e6 * dt / k_x, "algorithmic_bytes_per_env_step": b,
+                          "roofline_frac": n_x * k_x * b / dt / 1e9 / HBM_PEAK_GBS})
+            env.close()
+            del tape_x
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(rc)
@@ -196,9 +222,11 @@ def main():
                          "launches_timed": launches},
             "cpu_baseline": cpu,
             "fused_rollout": fused,
+            "extra_points": extra,
         }
         print(json.dumps(line), flush=True)
-    env.close()
+    if extra is None:
+        env.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
