@@ -139,8 +139,11 @@ DEV uint4 philox4x32_10(uint4 c, uint2 k) {
 DEV float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }             // [0,1)
 DEV float u01_open(uint32_t x) { return (float)((x >> 8) + 1u) * 5.9604644775390625e-08f; }  // (0,1]
 // Box-Muller on two 32-bit words; v_sin/v_cos take revolutions, so 2*pi*u needs no range reduction.
+// The radius uses the raw v_log_f32 (log2) and v_sqrt_f32: the argument is in [2^-24, 1], so none of the denormal / range
+// handling of logf() and the correctly rounded sqrtf() (a dozen compares, selects and ldexps per call) can trigger, and a
+// random variate needs no last-bit guarantee -- only determinism, which holds (the same function feeds hlx_fill_noise).
 DEV void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
-    float r = sqrtf(-2.0f * __logf(u01_open(a)));
+    float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01_open(a)));   // sqrt(-2 ln u)
     float u = u01(b);
     z0 = r * __builtin_amdgcn_cosf(u);
     z1 = r * __builtin_amdgcn_sinf(u);
@@ -171,7 +174,7 @@ DEV void gust_draws(const Rng& rng, V3& g, float& e) {
     float w_;
     box_muller(x.x, x.y, g.x, g.y);
     box_muller(x.z, x.w, g.z, w_);
-    e = -__logf(u01_open(y.x));
+    e = -0.6931471805599453f * __builtin_amdgcn_logf(u01_open(y.x));   // Exp(1) = -ln u
 }
 
 // ---------------------------------------------------------------------------------------------

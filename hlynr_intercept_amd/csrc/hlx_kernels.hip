@@ -48,6 +48,9 @@ namespace {
 // HLX_STAMPS=1: coarse map of the whole wave; HLX_STAMPS=2: slots 1..6 re-used for a close-up of one segment
 #define STAMP(k) do { if (HLX_STAMPS == 1 || (k) == 0 || (k) >= 7) STAMP_RAW(k); } while (0)
 #define STAMP2(k) do { if (HLX_STAMPS == 2) STAMP_RAW(k); } while (0)
+#elif defined(HLX_MARKS)   // listing-only build: section markers in the .s, for per-section instruction counts (tools/isa_sections.py)
+#define STAMP(k) asm volatile("; HLXMARK " #k)
+#define STAMP2(k) do { } while (0)
 #else
 #define STAMP(k) do { } while (0)
 #define STAMP2(k) do { } while (0)
