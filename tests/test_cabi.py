@@ -83,3 +83,18 @@ def test_vec_env_refuses_to_run_without_a_gpu():
     from hlynr_intercept_amd.vec_env import HlynrVecEnv
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         HlynrVecEnv(scenario_config("medium", "base"), num_envs=4)
+
+
+def test_product_package_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under hlynr_intercept_amd/ may import, load or link it, and the C ABI
+    library must not contain its entry points (no CPU fallback hiding in the product)."""
+    pkg = os.path.join(ROOT, "hlynr_intercept_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".inc")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, os.path.join(dirpath, f)
+                assert "orc_step" not in txt and "orc_reset" not in txt, os.path.join(dirpath, f)
+    lib = _lib.load()
+    for sym in ("orc_step", "orc_reset", "orc_step_batch", "hlx_step_cpu", "hlx_reset_cpu"):
+        assert not hasattr(lib, sym), sym
