@@ -618,6 +618,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
             if (HOT(opt.info.distance)) HOT(opt.info.distance)[i] = distance;
             if (HOT(opt.info.min_distance)) HOT(opt.info.min_distance)[i] = min_distance;
             if (HOT(opt.info.fuel)) HOT(opt.info.fuel)[i] = fuel;
+            if (HOT(opt.info.interceptor_pos)) {                                  // :836-838 (post-step, pre-respawn values)
+                float* ip = HOT(opt.info.interceptor_pos) + i;
+                ip[0] = ipos.x; ip[(size_t)n] = ipos.y; ip[2 * (size_t)n] = ipos.z;
+            }
+            if (HOT(opt.info.missile_pos)) {
+                float* mp = HOT(opt.info.missile_pos) + i;
+                mp[0] = mpos.x; mp[(size_t)n] = mpos.y; mp[2 * (size_t)n] = mpos.z;
+            }
+            if (HOT(opt.info.steps)) HOT(opt.info.steps)[i] = steps;
             if (HOT(opt.info.missiles)) {                                                 // :846-847
                 int remaining = intercepted ? 0 : 1, got = intercepted ? 1 : 0;
                 if (HAS(HLX_F_VOLLEY)) {

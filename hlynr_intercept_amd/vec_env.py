@@ -95,6 +95,10 @@ class LazyInfos(Sequence):
             # environment.py:844-847
             "volley_mode": h["volley"][0], "volley_size": h["volley"][1],
             "missiles_intercepted": int(h["missiles"][i]) & 15, "missiles_remaining": int(h["missiles"][i]) >> 4,
+            # environment.py:836-841 (read by train_hrl_pretrain.py:180-198, inference.py:535-560)
+            "interceptor_pos": h["interceptor_pos"][:, i].copy(), "missile_pos": h["missile_pos"][:, i].copy(),
+            "steps": int(h["steps"][i]), "fuel_used": float(100.0 - h["fuel"][i]),
+            "radar_quality": float(h["radar_quality"]) if flags & 32 else 0.0,
         }
         row = self._done.get(i)
         if row is not None:
@@ -144,10 +148,12 @@ class HlynrVecEnv:
                          fuel=torch.zeros(n, device=dev), flags=torch.zeros(n, dtype=torch.uint8, device=dev),
                          episode_return=torch.zeros(n, device=dev),
                          episode_length=torch.zeros(n, dtype=torch.int32, device=dev),
-                         missiles=torch.zeros(n, dtype=torch.uint8, device=dev))
+                         missiles=torch.zeros(n, dtype=torch.uint8, device=dev),
+                         interceptor_pos=torch.zeros((3, n), device=dev), missile_pos=torch.zeros((3, n), device=dev),
+                         steps=torch.zeros(n, dtype=torch.int32, device=dev))
         self._info_soa = _lib.HlxInfoSoa(*(self.info[k].data_ptr() for k in
                                            ("distance", "min_distance", "fuel", "flags", "episode_return",
-                                            "episode_length", "missiles")))
+                                            "episode_length", "missiles", "interceptor_pos", "missile_pos", "steps")))
         self._actions_dev = torch.zeros((n, _lib.ACT_DIM), dtype=torch.float32, device=dev)
         self._pending = None
         self._t_start = time.time()
@@ -258,6 +264,8 @@ class HlynrVecEnv:
         host = dict(terminated=term_h, truncated=trunc_h, distance=info["distance"].cpu().numpy(),
                     min_distance=info["min_distance"].cpu().numpy(), fuel=info["fuel"].cpu().numpy(),
                     flags=info["flags"].cpu().numpy(), t_start=self._t_start, missiles=info["missiles"].cpu().numpy(),
+                    interceptor_pos=info["interceptor_pos"].cpu().numpy(), missile_pos=info["missile_pos"].cpu().numpy(),
+                    steps=info["steps"].cpu().numpy(), radar_quality=self.rc.radar_quality,
                     volley=(bool(self.rc.volley_mode), int(self.rc.volley_size) if self.rc.volley_mode else 1))
         done_rows: Dict[int, int] = {}
         if n_done:

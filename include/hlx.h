@@ -123,6 +123,10 @@ typedef struct hlx_info_soa {
     int32_t *episode_length;  /* [N] written only for envs that finished this step (Monitor 'l') */
     uint8_t *missiles;        /* [N] low nibble info['missiles_intercepted'], high nibble info['missiles_remaining']
                                      (environment.py:846-847) */
+    float *interceptor_pos;   /* [3][N] plane-major x|y|z: info['interceptor_pos'] (environment.py:837; read by
+                                     train_hrl_pretrain.py:180-198, inference.py:535-560) */
+    float *missile_pos;       /* [3][N] plane-major: info['missile_pos'] = the priority missile (environment.py:836) */
+    int32_t *steps;           /* [N] info['steps'] (environment.py:838) */
 } hlx_info_soa;
 
 /* Logical per-environment state, array-of-struct, HOST memory: parity injection and checkpointing. */

@@ -150,6 +150,7 @@ def test_gpu_matches_reference_fixture(name):
     env.set_state(st)
 
     k_reset = 0
+    st_at = {int(t): j for j, t in enumerate(fx["st_index"])}
     worst = dict(obs=0.0, distance=0.0, reset_obs=0.0)
     rew_errs = []
     for t in range(T):
@@ -171,6 +172,11 @@ def test_gpu_matches_reference_fixture(name):
         rew_errs.append(float(np.max(_rel(rew_h, fx["reward"][t]))))
         worst["distance"] = max(worst["distance"], float(np.max(_rel(info["distance"].cpu().numpy(), fx["distance"][t]))))
         assert np.all(obs_h == obs_h[0:1]) and np.all(rew_h == rew_h[0]), "lanes with identical inputs diverged"
+        if t in st_at:   # info['interceptor_pos' | 'missile_pos' | 'steps'] = the post-step state of the (possibly finished) episode
+            j = st_at[t]
+            assert np.max(_rel(info["interceptor_pos"].cpu().numpy()[:, 0], fx["st_int_pos"][j])) <= 2 * RTOL, t
+            assert np.max(_rel(info["missile_pos"].cpu().numpy()[:, 0], fx["st_mis_pos"][j])) <= 2 * RTOL, t
+            assert int(info["steps"][0]) == int(fx["st_steps"][j]), t
         if fx["did_reset"][t]:
             worst["reset_obs"] = max(worst["reset_obs"], float(np.max(np.abs(obs_h - fx["reset_obs"][k_reset][None]))))
             k_reset += 1

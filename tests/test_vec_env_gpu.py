@@ -46,6 +46,23 @@ def test_sb3_vecenv_contract_and_auto_reset():
     env.close()
 
 
+def test_info_keys_the_reference_callers_read():
+    """train_hrl_pretrain.py:180-198 / inference.py:535-592 index infos[i] with these keys."""
+    env = _env(8)
+    env.reset()
+    obs, rew, dones, infos = env.step(np.zeros((8, 6), np.float32))
+    info = infos[3]
+    for key in ("distance", "intercepted", "missile_hit_target", "fuel_remaining", "fuel_used", "clamped", "interceptor_pos",
+                "missile_pos", "steps", "radar_detected", "radar_quality", "min_distance", "crossed_threshold",
+                "volley_mode", "volley_size", "missiles_intercepted", "missiles_remaining", "TimeLimit.truncated"):
+        assert key in info, key
+    assert info["interceptor_pos"].shape == (3,) and info["missile_pos"].shape == (3,) and info["steps"] == 1
+    st = env.get_state()
+    assert np.allclose(info["interceptor_pos"], list(st[3].int_pos)) and np.allclose(info["missile_pos"], list(st[3].mis_pos))
+    assert abs(float(np.linalg.norm(info["missile_pos"] - info["interceptor_pos"])) - info["distance"]) < 1e-2
+    env.close()
+
+
 def test_curriculum_hook_and_attrs():
     env = _env(8)
     assert env.get_current_intercept_radius() == 100.0
