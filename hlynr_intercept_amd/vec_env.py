@@ -50,6 +50,13 @@ except Exception:  # pragma: no cover - exercised where gymnasium is missing
         return _Box(low, high, shape)
 
 
+try:  # Stable-Baselines3 is optional (absent in the build image).  When it is there, the batched env IS an SB3 VecEnv:
+    # `PPO("MlpPolicy", envs)` wraps anything that is not an instance of its VecEnv class into a DummyVecEnv of one.
+    from stable_baselines3.common.vec_env import VecEnv as _SB3VecEnv
+except Exception:  # pragma: no cover - exercised where stable-baselines3 is missing
+    _SB3VecEnv = object
+
+
 class _ObservationGeneratorView:
     """`get_attr('observation_generator')[i]` (train_flat_ppo.py:224-232): curriculum-controlled radar knobs."""
 
@@ -112,7 +119,7 @@ class LazyInfos(Sequence):
         return [(i, self[i]) for i in sorted(self._done)]
 
 
-class HlynrVecEnv:
+class HlynrVecEnv(_SB3VecEnv):
     """N intercept environments on one MI355X, stepped by one fused HIP kernel per call."""
 
     metadata = {"render_modes": []}
@@ -160,6 +167,8 @@ class HlynrVecEnv:
         self._closed = False
         self._noise = None
         self.training_step_count = 0
+        if _SB3VecEnv is not object:   # SB3's own bookkeeping (reset_infos, _seeds, _options, render_mode)
+            _SB3VecEnv.__init__(self, self.num_envs, self.observation_space, self.action_space)
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):

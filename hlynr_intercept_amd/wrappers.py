@@ -23,7 +23,7 @@ from typing import Any, Optional
 import numpy as np
 
 from . import _lib
-from .vec_env import HlynrVecEnv, _box
+from .vec_env import HlynrVecEnv, _SB3VecEnv, _box
 
 
 class _RmsView:
@@ -41,8 +41,9 @@ class _RmsView:
     count = property(lambda s: s._get()[2])
 
 
-class _DeviceObsWrapper:
-    """Shared machinery: one `hlx_obs` pipeline behind one `HlynrVecEnv`."""
+class _DeviceObsWrapper(_SB3VecEnv):
+    """Shared machinery: one `hlx_obs` pipeline behind one `HlynrVecEnv`.  (An SB3 `VecEnv` where SB3 is installed, so
+    that `PPO(..., envs)` takes it as is; the SB3 constructor runs at the end of the concrete classes' __init__.)"""
 
     def __init__(self, venv, n_stack, norm_obs, norm_reward, training, clip_obs, clip_reward, gamma, epsilon):
         base = venv
@@ -70,6 +71,25 @@ class _DeviceObsWrapper:
         self._closed = False
 
     # ------------------------------------------------------------------ plumbing
+    def _sb3_init(self):
+        if _SB3VecEnv is not object:
+            _SB3VecEnv.__init__(self, self.num_envs, self.observation_space, self.action_space)
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        return self._base.env_method(method_name, *args, indices=indices, **kwargs)
+
+    def get_attr(self, attr_name, indices=None):
+        return self._base.get_attr(attr_name, indices)
+
+    def set_attr(self, attr_name, value, indices=None):
+        return self._base.set_attr(attr_name, value, indices)
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return self._base.env_is_wrapped(wrapper_class, indices)
+
+    def seed(self, seed=None):
+        return self._base.seed(seed)
+
     def _absorb(self, inner):
         """`VecNormalize(VecFrameStack(env))`: this pipeline does both jobs; the inner wrapper's handle is released."""
         inner._release()
@@ -174,6 +194,7 @@ class VecFrameStack(_DeviceObsWrapper):
                          gamma=0.99, epsilon=1e-8)
         self._training, self._norm_obs, self._norm_reward = False, False, False
         self.observation_space = _box(-2.0, 1.0, (self.feature_dim,))
+        self._sb3_init()
 
 
 class VecNormalize(_DeviceObsWrapper):
@@ -191,6 +212,7 @@ class VecNormalize(_DeviceObsWrapper):
         self.clip_obs, self.clip_reward, self.gamma, self.epsilon = float(clip_obs), float(clip_reward), float(gamma), float(epsilon)
         self.observation_space = _box(-2.0, 1.0, (self.feature_dim,))   # SB3 keeps the wrapped space
         self.obs_rms, self.ret_rms = _RmsView(self, "obs"), _RmsView(self, "ret")
+        self._sb3_init()
 
     training = property(lambda s: s._training)
     norm_obs = property(lambda s: s._norm_obs)
