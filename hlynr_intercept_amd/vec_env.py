@@ -308,6 +308,9 @@ class HlynrVecEnv(_SB3VecEnv):
             return [None] * len(idx)
         if method_name == "get_current_intercept_radius":  # environment.py:223
             return [self.get_current_intercept_radius()] * len(idx)
+        if method_name == "seed":                          # scripts/compare_policies.py:150
+            self.seed(*args, **kwargs)
+            return [None] * len(idx)
         raise AttributeError(f"env_method({method_name!r}) is not part of the batched environment")
 
     def get_attr(self, attr_name: str, indices=None) -> List[Any]:
