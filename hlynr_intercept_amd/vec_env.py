@@ -17,7 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import time
-from typing import Any, Dict, List, Optional, Sequence
+from typing import Any, Dict, List, Mapping, Optional, Sequence
 
 import numpy as np
 
@@ -114,9 +114,48 @@ class LazyInfos(Sequence):
                             "t": round(time.time() - h["t_start"], 6)}
         return d
 
+    def __iter__(self):
+        """Iteration (SB3's `for idx, info in enumerate(infos): info.get("episode")` runs every step over all N
+        environments) yields read-only views that materialise nothing until a key is asked for: environments that did not
+        finish answer `.get("episode")` / `.get("terminal_observation")` from the done-row table alone."""
+        done = self._done
+        for i in range(self._n):
+            yield _InfoView(self, i, done.get(i))
+
     def done_items(self):
         """(env index, info dict) for the envs that finished this step - what callbacks iterate over."""
         return [(i, self[i]) for i in sorted(self._done)]
+
+
+class _InfoView(Mapping):
+    """One environment's info as a read-only mapping; `dict(view)` or `infos[i]` gives the plain dict."""
+
+    __slots__ = ("_p", "_i", "_row")
+    _DONE_KEYS = ("terminal_observation", "episode")
+
+    def __init__(self, parent, i, row):
+        self._p, self._i, self._row = parent, i, row
+
+    def get(self, key, default=None):
+        if key in self._DONE_KEYS and self._row is None:
+            return default                      # the common case, answered without building anything
+        return self._p[self._i].get(key, default)
+
+    def __getitem__(self, key):
+        if key in self._DONE_KEYS and self._row is None:
+            raise KeyError(key)
+        return self._p[self._i][key]
+
+    def __contains__(self, key):
+        if key in self._DONE_KEYS:
+            return self._row is not None
+        return key in self._p[self._i]
+
+    def __iter__(self):
+        return iter(self._p[self._i])
+
+    def __len__(self):
+        return len(self._p[self._i])
 
 
 class HlynrVecEnv(_SB3VecEnv):

@@ -60,6 +60,10 @@ def test_info_keys_the_reference_callers_read():
     st = env.get_state()
     assert np.allclose(info["interceptor_pos"], list(st[3].int_pos)) and np.allclose(info["missile_pos"], list(st[3].mis_pos))
     assert abs(float(np.linalg.norm(info["missile_pos"] - info["interceptor_pos"])) - info["distance"]) < 1e-2
+    # iteration yields cheap read-only views (what SB3's per-step `for info in infos: info.get("episode")` touches)
+    views = list(infos)
+    assert len(views) == 8 and views[3].get("episode") is None and "terminal_observation" not in views[3]
+    assert views[3]["distance"] == info["distance"] and dict(views[3]).keys() == info.keys()
     env.close()
 
 
