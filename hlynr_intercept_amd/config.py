@@ -107,6 +107,7 @@ class ResolvedConfig:
     radar_beam_width: float = 60.0
     onboard_delay: int = 0            # samples; 0 = no delay ring (core.py:292-293)
     ground_enabled: bool = True       # a GroundRadarStation object exists (core.py:296-320)
+    ground_enabled_flag: bool = True  # `ground_radar_enabled` itself (core.py:296): True with an empty section too
     ground_pos: List[float] = field(default_factory=lambda: [0.0, 0.0, 100.0])
     ground_max_range: float = 20000.0
     ground_min_elev: float = math.radians(5.0)
@@ -290,6 +291,7 @@ def resolve_config(config: Optional[Dict[str, Any]] = None) -> ResolvedConfig:
     gr = config.get("ground_radar", {})
     ground_enabled_flag = gr.get("enabled", True) if gr else True
     rc.ground_enabled = bool(ground_enabled_flag and gr)   # core.py:296-320: empty dict -> no station object
+    rc.ground_enabled_flag = bool(ground_enabled_flag)
     if rc.ground_enabled:
         rc.ground_pos = [float(x) for x in gr.get("position", [0, 0, 100])]
         rc.ground_max_range = gr.get("max_range", 20000.0)

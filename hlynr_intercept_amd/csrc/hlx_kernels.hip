@@ -809,29 +809,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
                 const V3 rel = mpos - ipos;
                 const float range = snorm3(rel);
                 bool on_det = !(range > HOT(c.radar_range));                             // :539
+                float on_why = on_det ? 0.f : -1.f;   // detection_info['reason'] (:541,:555,:566), carried through the delay ring
                 STAMP2(3);  // close-up: range
                 const V3 fwd = forward_vec(q);
                 STAMP2(4);  // close-up: forward vector
                 {   // :546-553  arccos(clip(fwd . to_missile)) > half_beam  <=>  clip(fwd . to_missile) < cos(half_beam)
                     const float cb = clampf(fdot(fwd, rel) * __builtin_amdgcn_rcpf(range + 1e-6f), -1.f, 1.f);
-                    if (cb < HOT(cur.cos_half_beam)) on_det = false;
+                    if (on_det && cb < HOT(cur.cos_half_beam)) { on_det = false; on_why = -2.f; }
                 }
                 STAMP2(5);  // close-up: beam angle (acosf)
                 if (on_det) {                                                       // :559-566
                     float aq = (HOT(c.radar_quality) * (1.0f - (range * HOT(c.inv_radar_range)) * 0.5f)) * HOT(cur.on_rel);
-                    if (n_on > aq) on_det = false;
+                    if (n_on > aq) { on_det = false; on_why = -3.f; }
                 }
                 STAMP2(6);  // close-up: Bernoulli
                 V3 d_on = rel;
                 bool d_on_det = on_det;
                 if (HOT(c.o_delay) > 0) {                                                // :576-588 onboard delay ring
-                    on_sample = make_float4(rel.x, rel.y, rel.z, on_det ? 1.f : 0.f);
-                    d_on = v3(0.f, 0.f, 0.f); d_on_det = false;
+                    on_sample = make_float4(rel.x, rel.y, rel.z, on_det ? 1.f : on_why);   // w: 1 detected, -reason otherwise
+                    d_on = v3(0.f, 0.f, 0.f); d_on_det = false; on_why = -4.f;              // :582 'sensor_delay_initialization'
                     if (pass == 0 && steps >= on_delay) {
                         int slot = o_wslot - on_delay;                            // (t - on_delay) mod o_cap
                         slot += (slot < 0) ? o_cap : 0;
                         float4 s = oring[(size_t)slot * N + i];
-                        d_on = v3(s.x, s.y, s.z); d_on_det = s.w != 0.f;
+                        d_on = v3(s.x, s.y, s.z); d_on_det = s.w > 0.f; on_why = d_on_det ? 0.f : s.w;
                     }
                 }
                 STAMP(8);   // onboard detection + onboard ring
@@ -904,7 +905,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
                     float agree = 1.0f - fminf(fnorm(d_on - d_gp) * 0.005f, 1.0f);
                     fusion = clampf((float)(0.35 * HOT(c.radar_quality64)) + 0.50f * d_gq + 0.15f * agree, 0.f, 1.f);
                 }
-                if (pass == 0) det_bits = (d_on_det ? 32u : 0u) | (d_g_det ? 64u : 0u);
+                if (pass == 0) {
+                    det_bits = (d_on_det ? 32u : 0u) | (d_g_det ? 64u : 0u);
+                    if (HOT(opt.info.radar_debug)) {     // what info['radar_debug'] (core.py:650-683) cannot rebuild from positions
+                        float* rd = HOT(opt.info.radar_debug) + i;
+                        rd[0] = q.w; rd[N] = q.x; rd[2 * N] = q.y; rd[3 * N] = q.z;
+                        rd[4 * N] = d_gq;
+                        rd[5 * N] = __int_as_float((int)(-on_why) | (g_det ? 8 : 0));
+                        rd[6 * N] = datalink; rd[7 * N] = fusion;
+                    }
+                }
 
                 STAMP(10);  // datalink + fusion confidence
                 // ======================================================== core.py:693-1032 compute()

@@ -22,6 +22,7 @@ from typing import Any, Dict, List, Mapping, Optional, Sequence
 import numpy as np
 
 from . import _lib
+from .episode_log import radar_debug
 from .config import ResolvedConfig, resolve_config
 
 try:  # gymnasium is optional (absent in the build image); only `spaces.Box` is needed
@@ -108,6 +109,12 @@ class LazyInfos(Sequence):
             "radar_quality": float(h["radar_quality"]) if flags & 32 else 0.0,
         }
         row = self._done.get(i)
+        rd = h.get("radar")
+        if rd is not None:   # environment.py:842
+            p = rd["planes"]
+            d["radar_debug"] = radar_debug(rd["rc"], rd["beam_width"], d["interceptor_pos"], d["missile_pos"], p[0:4, i],
+                                           float(p[4, i]), int(p[5, i:i + 1].view(np.int32)[0]), flags, float(p[6, i]),
+                                           float(p[7, i]))
         if row is not None:
             d["terminal_observation"] = h["terminal_obs"][row]
             d["episode"] = {"r": float(h["ep_return"][row]), "l": int(h["ep_length"][row]),
@@ -164,7 +171,9 @@ class HlynrVecEnv(_SB3VecEnv):
     metadata = {"render_modes": []}
 
     def __init__(self, config: Optional[Dict[str, Any]] = None, num_envs: int = 16, device: int = 0, seed: int = 0,
-                 env_id_offset: int = 0, resolved: Optional[ResolvedConfig] = None):
+                 env_id_offset: int = 0, resolved: Optional[ResolvedConfig] = None, radar_debug: bool = False):
+        """radar_debug: also export what `info['radar_debug']` (environment.py:842) is assembled from, and add that key
+        to the info dicts (episode_log.radar_debug); off by default - eight more floats stored per env-step."""
         import torch
 
         if not torch.cuda.is_available():
@@ -197,9 +206,12 @@ class HlynrVecEnv(_SB3VecEnv):
                          missiles=torch.zeros(n, dtype=torch.uint8, device=dev),
                          interceptor_pos=torch.zeros((3, n), device=dev), missile_pos=torch.zeros((3, n), device=dev),
                          steps=torch.zeros(n, dtype=torch.int32, device=dev))
+        if radar_debug:
+            self.info["radar_debug"] = torch.zeros((8, n), device=dev)
         self._info_soa = _lib.HlxInfoSoa(*(self.info[k].data_ptr() for k in
                                            ("distance", "min_distance", "fuel", "flags", "episode_return",
-                                            "episode_length", "missiles", "interceptor_pos", "missile_pos", "steps")))
+                                            "episode_length", "missiles", "interceptor_pos", "missile_pos", "steps")),
+                                         self.info["radar_debug"].data_ptr() if radar_debug else None)
         self._actions_dev = torch.zeros((n, _lib.ACT_DIM), dtype=torch.float32, device=dev)
         self._pending = None
         self._t_start = time.time()
@@ -315,6 +327,9 @@ class HlynrVecEnv(_SB3VecEnv):
                     interceptor_pos=info["interceptor_pos"].cpu().numpy(), missile_pos=info["missile_pos"].cpu().numpy(),
                     steps=info["steps"].cpu().numpy(), radar_quality=self.rc.radar_quality,
                     volley=(bool(self.rc.volley_mode), int(self.rc.volley_size) if self.rc.volley_mode else 1))
+        if "radar_debug" in info:
+            host["radar"] = dict(planes=info["radar_debug"].cpu().numpy(), rc=self.rc,
+                                 beam_width=self.curriculum()["beam_width"])
         done_rows: Dict[int, int] = {}
         if n_done:
             idx = self.done_idx[:n_done].to(self._torch.int64)

@@ -371,6 +371,19 @@ def pursuit_action(env, rng, gain=1.0, jitter=0.2):
     return np.clip(a, -1, 1).astype(np.float32)
 
 
+RADAR_ONLY = False     # `make_golden.py radar`: re-run a case and keep only info['radar_debug'] per step (radar/<name>.npz)
+
+
+def _flatten(d, prefix=""):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out.update(_flatten(v, prefix + k + "."))
+        else:
+            out[prefix + k] = v
+    return out
+
+
 def run_case(name, env_cfg, n_steps, seed, policy="random", tweak=None, global_step=0, reseed_each_reset=False,
              state_every=1):
     from environment import InterceptEnvironment
@@ -467,6 +480,8 @@ def run_case(name, env_cfg, n_steps, seed, policy="random", tweak=None, global_s
         rec["info_min_distance"].append(np.float64(info["min_distance"]))
         rec["fuel_used"].append(np.float64(info["fuel_used"]))
         rec["radius"].append(np.float64(env.get_current_intercept_radius()))
+        if RADAR_ONLY:
+            rec.setdefault("radar", []).append(_flatten(info["radar_debug"]))
         if env.volley_mode:
             rec["missiles_intercepted"].append(np.int64(info["missiles_intercepted"]))
             rec["missiles_remaining"].append(np.int64(info["missiles_remaining"]))
@@ -483,6 +498,16 @@ def run_case(name, env_cfg, n_steps, seed, policy="random", tweak=None, global_s
             rec["reset_state"].append(capture_state(env))
         else:
             rec["did_reset"].append(False)
+    if RADAR_ONLY:
+        # same seeds, same draws: the trajectory must be the one already stored in <name>.npz
+        main = np.load(os.path.join(OUT, name + ".npz"))
+        assert np.array_equal(main["obs"], np.array(rec["obs"])), name + ": re-run differs from the stored fixture"
+        cols = {k: np.array([r[k] for r in rec["radar"]]) for k in rec["radar"][0]}
+        os.makedirs(os.path.join(OUT, "radar"), exist_ok=True)
+        np.savez_compressed(os.path.join(OUT, "radar", name + ".npz"), **cols)
+        reasons = {k: sorted(set(cols[k].tolist())) for k in cols if k.endswith("detection_reason")}
+        print(f"{name:34s} steps={n_steps:5d} radar_debug columns={len(cols)} reasons={reasons}")
+        return
     og = env.observation_generator
     gr = og.ground_radar
     effective = dict(
@@ -633,6 +658,9 @@ def main():
     np.random.randn = _rec_randn
     _selfcheck_wrappers()
     S = scenario_config
+    if len(sys.argv) > 1 and sys.argv[1] == "radar":
+        radar_cases(S)       # adds / refreshes radar/<name>.npz for a few of the cases below
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "volley":
         volley_cases(S)      # adds / refreshes the volley fixtures only
         return
@@ -697,6 +725,26 @@ def main():
              policy=spin_then_random)
     run_case("edge_no_ground_radar", S("medium", "base", {"ground_radar": {"enabled": False}}), 100, 1062)
     volley_cases(S)
+
+
+def radar_cases(S):
+    """info['radar_debug'] (environment.py:842, core.py:650-683) of cases that already have a fixture: every
+    detection_reason of both radars, the delay lines, the radar curriculum, volley priority switching."""
+    global RADAR_ONLY
+    RADAR_ONLY = True
+    V = lambda k, extra=None: dict({"volley_mode": True, "volley_size": k}, **(extra or {}))  # noqa: E731
+    run_case("medium_base_random", S("medium", "base"), 400, 1001)
+    run_case("medium_v2_random", S("medium", "v2"), 400, 1002)
+    run_case("medium_base_short_eps", S("medium", "base", {"max_steps": 60}), 400, 1010)
+    run_case("edge_ground_hit_near", S("medium", "base"), 40, 1052, tweak=tw_missile_low_near)
+    run_case("edge_ground_hit_far", S("medium", "v2"), 40, 1053, tweak=tw_missile_low_far)
+    run_case("edge_look_away", S("medium", "v2"), 120, 1058, tweak=tw_look_away, policy="coast")
+    run_case("edge_blind_kf_uninit", S("medium", "v2"), 80, 1060, tweak=tw_blind, policy="coast")
+    run_case("edge_radar_curriculum_mid", S("medium", "base"), 120, 1061, global_step=6500000,
+             policy=spin_then_random)
+    run_case("edge_no_ground_radar", S("medium", "base", {"ground_radar": {"enabled": False}}), 100, 1062)
+    run_case("volley3_medium_base_random", S("medium", "base", V(3)), 400, 1100)
+    RADAR_ONLY = False
 
 
 def tw_volley_ground(env):

@@ -187,3 +187,63 @@ def _merge(res, errs, where):
             res["int_mismatch"].append((where, k, v))
         else:
             res["state"][k] = max(res["state"].get(k, 0.0), v)
+
+
+# ---- info['radar_debug'] fixtures (tests/golden/radar/<name>.npz, recorded by `make_golden.py radar`) ----------
+def radar_fixture_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "radar", "*.npz")))
+
+
+def load_radar_fixture(name):
+    p = os.path.join(GOLDEN, "radar", name + ".npz")
+    if not os.path.exists(p):
+        return None
+    d = np.load(p, allow_pickle=False)
+    return {k: d[k] for k in d.files}
+
+
+RADAR_ANGLE_ATOL_DEG = 0.05   # arccos of a float32 cosine near 1: 1e-7 of cosine is ~0.03 degrees of angle
+RADAR_RTOL = 2e-5             # positions / ranges: same bound as info['interceptor_pos'] in the step parity tests
+
+
+def compare_radar_debug(mine, cols, t, skip_onboard_reason=False):
+    """One step's `info['radar_debug']` dict against the reference's (flattened columns, row t).  Returns a list of
+    mismatch descriptions (empty = equal within the tolerances above; strings and booleans must be identical)."""
+    bad = []
+
+    def num(key, tol, rel=False):
+        a = np.asarray(_dig(mine, key), np.float64)
+        b = np.asarray(cols[key][t], np.float64)
+        err = np.max(np.abs(a - b) / (np.maximum(1.0, np.abs(b)) if rel else 1.0))
+        if not err <= tol:
+            bad.append((t, key, a.tolist(), b.tolist()))
+
+    def same(key):
+        a, b = _dig(mine, key), cols[key][t]
+        b = b.item() if hasattr(b, "item") else b
+        if a != b:
+            bad.append((t, key, a, b))
+
+    for key in ("onboard.position", "onboard.range_to_target", "ground.range_to_target"):
+        num(key, RADAR_RTOL, rel=True)
+    num("onboard.forward_vector", 1e-5)
+    num("onboard.beam_angle_to_target_deg", RADAR_ANGLE_ATOL_DEG)
+    num("ground.elevation_deg", 1e-3)
+    for key in ("onboard.beam_width_deg", "onboard.half_beam_width_deg", "onboard.max_range", "onboard.quality",
+                "ground.position", "ground.max_range", "ground.min_elevation_deg", "ground.max_elevation_deg",
+                "ground.quality", "fusion.datalink_quality", "fusion.fusion_confidence"):
+        num(key, 1e-5, rel=True)
+    if abs(float(cols["onboard.beam_angle_to_target_deg"][t]) - float(cols["onboard.half_beam_width_deg"][t])) > RADAR_ANGLE_ATOL_DEG:
+        same("onboard.in_beam")
+    for key in ("onboard.detected", "ground.enabled", "ground.detected", "ground.detection_reason",
+                "fusion.both_detected", "fusion.any_detected"):
+        same(key)
+    if not skip_onboard_reason:
+        same("onboard.detection_reason")
+    return bad
+
+
+def _dig(d, dotted):
+    for k in dotted.split("."):
+        d = d[k]
+    return d

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from tests.golden_util import fixture_names, load_fixture
+from tests.golden_util import compare_radar_debug, fixture_names, load_fixture, load_radar_fixture
 
 pytestmark = pytest.mark.gpu
 
@@ -83,9 +83,9 @@ def _torch():
     return torch
 
 
-def _make_env(rc, n, global_step=None, seed=0, offset=0):
+def _make_env(rc, n, global_step=None, seed=0, offset=0, radar_debug=False):
     from hlynr_intercept_amd.vec_env import HlynrVecEnv
-    env = HlynrVecEnv(resolved=rc, num_envs=n, seed=seed, env_id_offset=offset)
+    env = HlynrVecEnv(resolved=rc, num_envs=n, seed=seed, env_id_offset=offset, radar_debug=radar_debug)
     if global_step is not None:
         env.set_training_step_count(global_step)
     return env
@@ -107,9 +107,11 @@ def test_gpu_matches_reference_fixture(name):
     fx = load_fixture(name)
     rc = resolve_config(fx["config"])
     n = 3   # same inputs in three lanes: also checks lane independence
-    env = _make_env(rc, n, fx["global_step_or_none"])
+    radar = load_radar_fixture(name)   # info['radar_debug'] of every step, for the cases that have it recorded
+    env = _make_env(rc, n, fx["global_step_or_none"], radar_debug=radar is not None)
     dev = env.device
     T = len(fx["action"])
+    radar_bad = []
     from hlynr_intercept_amd import _lib as hl
     S, R = hl.STEP_SLOTS, hl.RESET_SLOTS
 
@@ -172,6 +174,13 @@ def test_gpu_matches_reference_fixture(name):
         rew_errs.append(float(np.max(_rel(rew_h, fx["reward"][t]))))
         worst["distance"] = max(worst["distance"], float(np.max(_rel(info["distance"].cpu().numpy(), fx["distance"][t]))))
         assert np.all(obs_h == obs_h[0:1]) and np.all(rew_h == rew_h[0]), "lanes with identical inputs diverged"
+        if radar is not None:   # environment.py:842 <- core.py:650-683, rebuilt from the kernel's side outputs
+            from hlynr_intercept_amd.episode_log import radar_debug
+            p = info["radar_debug"].cpu().numpy()
+            mine = radar_debug(rc, env.curriculum()["beam_width"], info["interceptor_pos"].cpu().numpy()[:, 0],
+                               info["missile_pos"].cpu().numpy()[:, 0], p[0:4, 0], float(p[4, 0]),
+                               int(p[5, 0:1].view(np.int32)[0]), int(flags[0]), float(p[6, 0]), float(p[7, 0]))
+            radar_bad += compare_radar_debug(mine, radar, t)
         if t in st_at:   # info['interceptor_pos' | 'missile_pos' | 'steps'] = the post-step state of the (possibly finished) episode
             j = st_at[t]
             assert np.max(_rel(info["interceptor_pos"].cpu().numpy()[:, 0], fx["st_int_pos"][j])) <= 2 * RTOL, t
@@ -182,6 +191,7 @@ def test_gpu_matches_reference_fixture(name):
             k_reset += 1
     assert worst["obs"] <= OBS_ATOL, worst
     assert worst["reset_obs"] <= OBS_ATOL, worst
+    assert not radar_bad, (len(radar_bad), radar_bad[:5])
     _check_reward_errors(rew_errs, rc, name)
     assert worst["distance"] <= RTOL, worst
     # final state vs the recorded reference state

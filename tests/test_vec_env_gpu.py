@@ -67,6 +67,55 @@ def test_info_keys_the_reference_callers_read():
     env.close()
 
 
+def test_radar_debug_key_and_episode_files(tmp_path):
+    """inference.py:535-548 logs info['radar_debug'] (environment.py:842) next to the two positions; the key is opt-in."""
+    import json
+    import os
+
+    from hlynr_intercept_amd.episode_log import VecEpisodeRecorder
+    from hlynr_intercept_amd.scenarios import scenario_config
+    from hlynr_intercept_amd.vec_env import HlynrVecEnv
+
+    plain = _env(4)
+    plain.reset()
+    assert "radar_debug" not in plain.step(np.zeros((4, 6), np.float32))[3][0]
+    plain.close()
+    n = 70   # two workgroups, the second one partial
+    env = HlynrVecEnv(scenario_config("medium", "v2", {"max_steps": 25}), num_envs=n, seed=3, radar_debug=True)
+    env.reset()
+    rec = VecEpisodeRecorder(str(tmp_path), indices=(1, 69), run_name="gpu")
+    rng = np.random.default_rng(0)
+    reasons = set()
+    for t in range(60):
+        a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+        obs, rew, dones, infos = env.step(a)
+        rec.on_step(a, rew, dones, infos)
+        for i in (0, 1, 64, 69):
+            info = infos[i]
+            rd = info["radar_debug"]
+            assert rd["onboard"]["position"] == info["interceptor_pos"].tolist()
+            assert rd["onboard"]["detected"] == info["radar_detected"] and rd["ground"]["detected"] == info["ground_radar_detected"]
+            assert abs(rd["onboard"]["range_to_target"] - info["distance"]) <= 1e-3 * max(1.0, info["distance"])
+            step_obs = info["terminal_observation"] if dones[i] else obs[i]
+            assert rd["fusion"]["datalink_quality"] == float(step_obs[24]) and rd["fusion"]["fusion_confidence"] == float(step_obs[25])
+            assert abs(np.linalg.norm(rd["onboard"]["forward_vector"]) - 1.0) < 1e-4
+            if info["steps"] < env.rc.onboard_delay:      # the delay line is still filling (core.py:576-582)
+                assert rd["onboard"]["detection_reason"] == "sensor_delay_initialization" and not rd["onboard"]["detected"]
+            reasons.add(rd["onboard"]["detection_reason"])
+            reasons.add(rd["ground"]["detection_reason"])
+    rec.close()
+    assert {"detected", "sensor_delay_initialization"} <= reasons and "unknown" in reasons
+    assert len(rec.results) == 4 and all(r["steps"] == 25 for r in rec.results)     # two episodes per watched env
+    d = os.path.join(rec._logs[69].log_dir, "episodes")
+    assert sorted(os.listdir(d)) == ["ep_0000.jsonl", "ep_0001.jsonl", "ep_0002.jsonl"]
+    with open(os.path.join(d, "ep_0001.jsonl")) as f:
+        rows = [json.loads(line) for line in f]
+    assert rows[0]["type"] == "header" and rows[-1]["type"] == "footer" and rows[-1]["metrics"]["steps"] == 25
+    assert [r["entity_id"] for r in rows[1:-1]] == ["interceptor", "missile", "radar"] * 25
+    assert rows[3]["state"]["ground"]["max_range"] == 20000.0
+    env.close()
+
+
 def test_curriculum_hook_and_attrs():
     env = _env(8)
     assert env.get_current_intercept_radius() == 100.0
