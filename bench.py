@@ -130,6 +130,7 @@ def main():
     assert count == n
     env = HlynrVecEnv(resolved=rc, num_envs=n, device=local_rank, seed=1000, env_id_offset=offset)
     dev = env.device
+    variant = env.kernel_variant      # read now: the handle is gone once the extra points have run
     K, W = args.steps, args.warmup
     gen = torch.Generator(device=dev).manual_seed(rank)      # fixed-seed synthetic action tape, U(-1, 1)
     tape_len = max(K, W, 1)
@@ -213,11 +214,11 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"medium scenario, {args.physics} physics, {n} envs/GPU, fp32 "
                                    f"(BASELINE.json configs[{1 if args.physics == 'base' else 2}])",
-                       "envs_per_gpu": n, "kernel_variant": env.kernel_variant, "launches_per_step": 1,
+                       "envs_per_gpu": n, "kernel_variant": variant, "launches_per_step": 1,
                        "sharding": f"{world} x {n} independent envs, no collective in the step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.physics, n),
-                         "kernel": "hlx_env_kernel<%s, step>" % env.kernel_variant,
+                         "kernel": "hlx_env_kernel<%s, step>" % variant,
                          "kernel_us": kern_us, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "launches_timed": launches},
             "cpu_baseline": cpu,

@@ -20,6 +20,7 @@ F_ATMOSPHERE, F_MACH_DRAG, F_ENH_WIND, F_THRUST_LAG, F_DOMAIN_RAND, F_VALIDATION
 F_PROX_FUZE, F_GROUND, F_SPHERICAL, F_TOWARD_MISSILE, F_OBS_BODY, F_OBS_LOS, F_USE_CURRICULUM, F_RADAR_CURRICULUM = (
     1 << 8, 1 << 9, 1 << 10, 1 << 11, 1 << 12, 1 << 13, 1 << 14, 1 << 15)
 F_VOLLEY = 1 << 16
+F_RADAR_DEBUG = 1 << 17
 
 
 class HlxConfig(C.Structure):

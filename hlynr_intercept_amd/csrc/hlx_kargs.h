@@ -13,7 +13,7 @@ constexpr uint32_t KF_DYNAMIC = 1u << 31;
 constexpr uint32_t KF_CODEGEN_MASK = HLX_F_ATMOSPHERE | HLX_F_MACH_DRAG | HLX_F_ENH_WIND | HLX_F_THRUST_LAG |
                                      HLX_F_DOMAIN_RAND | HLX_F_VALIDATION | HLX_F_EVASION | HLX_F_PRECISION |
                                      HLX_F_PROX_FUZE | HLX_F_GROUND | HLX_F_SPHERICAL | HLX_F_TOWARD_MISSILE |
-                                     HLX_F_OBS_BODY | HLX_F_OBS_LOS | HLX_F_VOLLEY;
+                                     HLX_F_OBS_BODY | HLX_F_OBS_LOS | HLX_F_VOLLEY | HLX_F_RADAR_DEBUG;
 
 // State arena: 16-byte groups, blocked struct-of-arrays: arena[env / 64][group][env % 64].  Every load/store
 // of a group is one 16-byte-per-lane, 1-KiB-per-wave coalesced access, and a wave's whole state is one

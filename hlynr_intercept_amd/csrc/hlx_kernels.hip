@@ -826,7 +826,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
                 V3 d_on = rel;
                 bool d_on_det = on_det;
                 if (HOT(c.o_delay) > 0) {                                                // :576-588 onboard delay ring
-                    on_sample = make_float4(rel.x, rel.y, rel.z, on_det ? 1.f : on_why);   // w: 1 detected, -reason otherwise
+                    on_sample = make_float4(rel.x, rel.y, rel.z, on_det ? 1.f : (HAS(HLX_F_RADAR_DEBUG) ? on_why : 0.f));   // w: 1 detected, -reason otherwise
                     d_on = v3(0.f, 0.f, 0.f); d_on_det = false; on_why = -4.f;              // :582 'sensor_delay_initialization'
                     if (pass == 0 && steps >= on_delay) {
                         int slot = o_wslot - on_delay;                            // (t - on_delay) mod o_cap
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
                 }
                 if (pass == 0) {
                     det_bits = (d_on_det ? 32u : 0u) | (d_g_det ? 64u : 0u);
-                    if (HOT(opt.info.radar_debug)) {     // what info['radar_debug'] (core.py:650-683) cannot rebuild from positions
+                    if (HAS(HLX_F_RADAR_DEBUG) && HOT(opt.info.radar_debug)) {     // what info['radar_debug'] (core.py:650-683) cannot rebuild from positions
                         float* rd = HOT(opt.info.radar_debug) + i;
                         rd[0] = q.w; rd[N] = q.x; rd[2 * N] = q.y; rd[3 * N] = q.z;
                         rd[4 * N] = d_gq;

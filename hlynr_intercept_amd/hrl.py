@@ -64,6 +64,7 @@ class HRLController:
         if not self._closed and self._h:
             self._torch.cuda.synchronize(self.device)
             self._lib.hlx_hrl_destroy(self._h)
+            self._h = C.c_void_p()
             self._closed = True
 
     def __del__(self):  # pragma: no cover

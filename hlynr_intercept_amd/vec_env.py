@@ -173,7 +173,7 @@ class HlynrVecEnv(_SB3VecEnv):
     def __init__(self, config: Optional[Dict[str, Any]] = None, num_envs: int = 16, device: int = 0, seed: int = 0,
                  env_id_offset: int = 0, resolved: Optional[ResolvedConfig] = None, radar_debug: bool = False):
         """radar_debug: also export what `info['radar_debug']` (environment.py:842) is assembled from, and add that key
-        to the info dicts (episode_log.radar_debug); off by default - eight more floats stored per env-step."""
+        to the info dicts (episode_log.radar_debug); off by default - eight more floats stored per env-step, and the generic kernel variant."""
         import torch
 
         if not torch.cuda.is_available():
@@ -188,6 +188,8 @@ class HlynrVecEnv(_SB3VecEnv):
         self.action_space = _box(-1.0, 1.0, (_lib.ACT_DIM,))          # environment.py:195-197
         self._lib = _lib.load()
         self._cfg = _lib.make_hlx_config(self.rc)
+        if radar_debug:
+            self._cfg.flags |= _lib.F_RADAR_DEBUG      # generic kernel variant: the specialised ones carry no debug export
         self._h = C.c_void_p()
         _lib.check(self._lib.hlx_create(C.byref(self._cfg), self.num_envs, self.device_index, int(seed),
                                         int(env_id_offset), C.byref(self._h)))
@@ -229,6 +231,7 @@ class HlynrVecEnv(_SB3VecEnv):
         if not self._closed and self._h:
             self._torch.cuda.synchronize(self.device)
             self._lib.hlx_destroy(self._h)
+            self._h = C.c_void_p()      # later calls fail with "null handle" instead of touching freed memory
             self._closed = True
 
     def __del__(self):  # pragma: no cover
@@ -239,6 +242,8 @@ class HlynrVecEnv(_SB3VecEnv):
 
     @property
     def kernel_variant(self) -> str:
+        if self._closed:
+            raise RuntimeError("kernel_variant: the environment is closed")
         return self._lib.hlx_kernel_variant(self._h).decode()
 
     # ------------------------------------------------------------------ torch / gymnasium-vector style API

@@ -98,6 +98,7 @@ class _DeviceObsWrapper(_SB3VecEnv):
         if not self._closed and self._p:
             self._torch.cuda.synchronize(self.device)
             self._lib.hlx_obs_destroy(self._p)
+            self._p = C.c_void_p()
             self._closed = True
 
     def close(self):

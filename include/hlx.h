@@ -77,8 +77,11 @@ typedef enum hlx_flags {
     HLX_F_OBS_LOS = 1u << 13,      /* observation_mode los_frame + LOS action transform  core.py:791-868, environment.py:965-1063 */
     HLX_F_USE_CURRICULUM = 1u << 14, /* intercept-radius curriculum     environment.py:223-234 */
     HLX_F_RADAR_CURRICULUM = 1u << 15, /* radar curriculum dict non-empty environment.py:274-351 */
-    HLX_F_VOLLEY = 1u << 16        /* volley_mode: volley_size missiles per episode  environment.py:236-267, 386-439,
+    HLX_F_VOLLEY = 1u << 16,       /* volley_mode: volley_size missiles per episode  environment.py:236-267, 386-439,
                                       470-487, 631-692, 724-748 */
+    HLX_F_RADAR_DEBUG = 1u << 17   /* keep what info['radar_debug'] (core.py:650-683) needs: the onboard detection reason
+                                      travels through the delay ring and hlx_info_soa.radar_debug may be given.  Selects
+                                      the generic kernel variant; the specialised ones carry none of it. */
 } hlx_flags;
 
 /* Flat parameter set = the EFFECTIVE values the reference's constructor arrives at
@@ -133,7 +136,8 @@ typedef struct hlx_info_soa {
                                      (0 none/detected, 1 out_of_range, 2 outside_beam, 3 poor_signal,
                                      4 sensor_delay_initialization), bit3 the ground radar detected THIS step (before its
                                      delay line); 6 data-link quality, 7 fusion confidence (observation entries 24, 25
-                                     of this step).  hlynr_intercept_amd/episode_log.py assembles the dict. */
+                                     of this step).  Requires HLX_F_RADAR_DEBUG (hlx_step fails otherwise).
+                                     hlynr_intercept_amd/episode_log.py assembles the dict. */
 } hlx_info_soa;
 
 /* Logical per-environment state, array-of-struct, HOST memory: parity injection and checkpointing. */
@@ -149,8 +153,8 @@ typedef struct hlx_env_state {
     double kf_x[6];
     float kf_P[4];                      /* p_pp, p_pv, p_vp, p_vv : covariance is 3 identical 2x2 blocks */
     int32_t on_delay, on_len;
-    float on_ring[HLX_RING_CAP][4];     /* oldest -> newest : rel_pos xyz, then 1 = detected, otherwise minus the
-                                           detection_reason code of hlx_info_soa.radar_debug (0 = not recorded) */
+    float on_ring[HLX_RING_CAP][4];     /* oldest -> newest : rel_pos xyz, then 1 = detected, otherwise 0, or with
+                                           HLX_F_RADAR_DEBUG minus the detection_reason code of hlx_info_soa.radar_debug */
     int32_t g_len;
     double g_ring[HLX_RING_CAP][8];     /* oldest -> newest : rel_pos xyz (float64 measurement), quality, rel_vel xyz,
                                            sample-was-a-detection flag */

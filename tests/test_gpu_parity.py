@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from tests.golden_util import compare_radar_debug, fixture_names, load_fixture, load_radar_fixture
+from tests.golden_util import compare_radar_debug, fixture_names, load_fixture, load_radar_fixture, radar_fixture_names
 
 pytestmark = pytest.mark.gpu
 
@@ -101,13 +101,37 @@ def _rel(a, b):
 # ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", fixture_names())
 def test_gpu_matches_reference_fixture(name):
+    _replay_fixture(name, None)
+
+
+@pytest.mark.parametrize("name", radar_fixture_names())
+def test_gpu_radar_debug_matches_reference(name):
+    """Same replay with HLX_F_RADAR_DEBUG (generic kernel variant + debug planes): everything above still holds and
+    info['radar_debug'] of every step equals the reference's recorded dict (tests/golden/radar)."""
+    _replay_fixture(name, load_radar_fixture(name))
+
+
+def test_radar_planes_need_the_flag():
+    from hlynr_intercept_amd import _lib as hl
+    from hlynr_intercept_amd.config import resolve_config
+    from hlynr_intercept_amd.scenarios import scenario_config
+    torch = _torch()
+    env = _make_env(resolve_config(scenario_config("medium", "base")), 4)
+    env.reset_torch()
+    env.info["radar_debug"] = torch.zeros((8, 4), device=env.device)
+    env._info_soa.radar_debug = env.info["radar_debug"].data_ptr()
+    with pytest.raises(hl.HlxError, match="HLX_F_RADAR_DEBUG"):
+        env.step_torch(torch.zeros((4, 6), device=env.device))
+    env.close()
+
+
+def _replay_fixture(name, radar):
     torch = _torch()
     from hlynr_intercept_amd.config import resolve_config
 
     fx = load_fixture(name)
     rc = resolve_config(fx["config"])
     n = 3   # same inputs in three lanes: also checks lane independence
-    radar = load_radar_fixture(name)   # info['radar_debug'] of every step, for the cases that have it recorded
     env = _make_env(rc, n, fx["global_step_or_none"], radar_debug=radar is not None)
     dev = env.device
     T = len(fx["action"])

@@ -116,6 +116,21 @@ def test_radar_debug_key_and_episode_files(tmp_path):
     env.close()
 
 
+def test_closed_environment_fails_loudly():
+    """A destroyed handle must not be dereferenced: calls after close() raise instead of reading freed memory."""
+    env = _env(8)
+    env.reset()
+    assert env.kernel_variant
+    env.close()
+    env.close()      # idempotent
+    with pytest.raises(RuntimeError):
+        env.kernel_variant
+    with pytest.raises(RuntimeError, match="null handle"):
+        env.step(np.zeros((8, 6), np.float32))
+    with pytest.raises(RuntimeError, match="null"):
+        env.curriculum()
+
+
 def test_curriculum_hook_and_attrs():
     env = _env(8)
     assert env.get_current_intercept_radius() == 100.0
