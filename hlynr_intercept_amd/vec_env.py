@@ -58,6 +58,9 @@ except Exception:  # pragma: no cover - exercised where stable-baselines3 is mis
     _SB3VecEnv = object
 
 
+_NP_DTYPES: Dict[Any, Any] = {}     # torch dtype -> numpy dtype, filled on first use (torch is imported lazily)
+
+
 class _ObservationGeneratorView:
     """`get_attr('observation_generator')[i]` (train_flat_ppo.py:224-232): curriculum-controlled radar knobs."""
 
@@ -195,26 +198,38 @@ class HlynrVecEnv(_SB3VecEnv):
                                         int(env_id_offset), C.byref(self._h)))
         n, dev = self.num_envs, self.device
         self.obs = torch.zeros((n, _lib.OBS_DIM), dtype=torch.float32, device=dev)
-        self.reward = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.terminated = torch.zeros(n, dtype=torch.uint8, device=dev)
-        self.truncated = torch.zeros(n, dtype=torch.uint8, device=dev)
+        # Per-step scalar outputs live in ONE device slab (256-byte aligned typed views), so that the numpy path brings
+        # them to the host with a single copy instead of a dozen.
+        f32, u8, i32 = torch.float32, torch.uint8, torch.int32
+        _NP_DTYPES.update({f32: np.float32, u8: np.uint8, i32: np.int32})
+        spec = [("reward", f32, (n,)), ("terminated", u8, (n,)), ("truncated", u8, (n,)), ("n_done", i32, (1,)),
+                ("distance", f32, (n,)), ("min_distance", f32, (n,)), ("fuel", f32, (n,)), ("flags", u8, (n,)),
+                ("missiles", u8, (n,)), ("interceptor_pos", f32, (3, n)), ("missile_pos", f32, (3, n)), ("steps", i32, (n,))]
+        if radar_debug:
+            spec.append(("radar_debug", f32, (8, n)))
+        self._slab_layout, off = {}, 0
+        for name, dt, shape in spec:
+            nbytes = int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()
+            self._slab_layout[name] = (off, nbytes, dt, shape)
+            off += (nbytes + 255) // 256 * 256
+        self._slab = torch.zeros(off, dtype=u8, device=dev)
+        v = {name: self._slab[o:o + nb].view(dt).view(shape) for name, (o, nb, dt, shape) in self._slab_layout.items()}
+        self.reward, self.terminated, self.truncated, self.n_done = v["reward"], v["terminated"], v["truncated"], v["n_done"]
         self.terminal_obs = torch.zeros((n, _lib.OBS_DIM), dtype=torch.float32, device=dev)
         self.done_idx = torch.zeros(n, dtype=torch.int32, device=dev)
-        self.n_done = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.info = dict(distance=torch.zeros(n, device=dev), min_distance=torch.zeros(n, device=dev),
-                         fuel=torch.zeros(n, device=dev), flags=torch.zeros(n, dtype=torch.uint8, device=dev),
+        self.info = dict(distance=v["distance"], min_distance=v["min_distance"], fuel=v["fuel"], flags=v["flags"],
                          episode_return=torch.zeros(n, device=dev),
                          episode_length=torch.zeros(n, dtype=torch.int32, device=dev),
-                         missiles=torch.zeros(n, dtype=torch.uint8, device=dev),
-                         interceptor_pos=torch.zeros((3, n), device=dev), missile_pos=torch.zeros((3, n), device=dev),
-                         steps=torch.zeros(n, dtype=torch.int32, device=dev))
+                         missiles=v["missiles"], interceptor_pos=v["interceptor_pos"], missile_pos=v["missile_pos"],
+                         steps=v["steps"])
         if radar_debug:
-            self.info["radar_debug"] = torch.zeros((8, n), device=dev)
+            self.info["radar_debug"] = v["radar_debug"]
         self._info_soa = _lib.HlxInfoSoa(*(self.info[k].data_ptr() for k in
                                            ("distance", "min_distance", "fuel", "flags", "episode_return",
                                             "episode_length", "missiles", "interceptor_pos", "missile_pos", "steps")),
                                          self.info["radar_debug"].data_ptr() if radar_debug else None)
         self._actions_dev = torch.zeros((n, _lib.ACT_DIM), dtype=torch.float32, device=dev)
+        self._actions_pin = torch.zeros((n, _lib.ACT_DIM), dtype=torch.float32, pin_memory=True)
         self._pending = None
         self._t_start = time.time()
         self._closed = False
@@ -305,11 +320,18 @@ class HlynrVecEnv(_SB3VecEnv):
         return self.reset_torch().cpu().numpy()
 
     def step_async(self, actions):
-        a = np.ascontiguousarray(actions, dtype=np.float32)
+        if self._pending is not None:
+            raise RuntimeError("step_async() called twice without step_wait()")
+        self._pending = self.step_torch(self._upload_actions(actions), want_done_list=True)
+
+    def _upload_actions(self, actions):
+        """Host action batch -> the device action buffer (pinned staging, stream-ordered before the step kernel)."""
+        a = np.asarray(actions)
         if a.shape != (self.num_envs, _lib.ACT_DIM):
             raise ValueError(f"actions must have shape ({self.num_envs}, {_lib.ACT_DIM}), got {a.shape}")
-        self._actions_dev.copy_(self._torch.from_numpy(a))
-        self._pending = self.step_torch(self._actions_dev, want_done_list=True)
+        np.copyto(self._actions_pin.numpy(), a, casting="unsafe")      # one pass: dtype cast + staging
+        self._actions_dev.copy_(self._actions_pin, non_blocking=True)
+        return self._actions_dev
 
     def step_wait(self):
         if self._pending is None:
@@ -320,21 +342,37 @@ class HlynrVecEnv(_SB3VecEnv):
 
     def _materialise(self, obs, rew, term, trunc, info, terminal):
         """Device step results -> the numpy (obs, rewards, dones, infos) tuple SB3 expects (one D2H copy each)."""
-        obs_h = obs.cpu().numpy()
-        rew_h = rew.cpu().numpy()
-        term_h = term.cpu().numpy().astype(bool)
-        trunc_h = trunc.cpu().numpy().astype(bool)
+        torch = self._torch
+
+        def d2h(t):   # pinned staging (torch's caching host allocator recycles the blocks), all copies in flight at once
+            h = torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            return h
+
+        # the slab (every per-step scalar plane) in one copy, the observation batch in another; a wrapper's own reward /
+        # done tensors (e.g. normalised rewards) are fetched separately
+        slab_h, obs_t = d2h(self._slab), d2h(obs)
+        own = {name: d2h(t) for name, t, mine in (("reward", rew, self.reward), ("terminated", term, self.terminated),
+                                                   ("truncated", trunc, self.truncated)) if t.data_ptr() != mine.data_ptr()}
+        torch.cuda.current_stream(self.device).synchronize()
+        slab_np = slab_h.numpy()
+
+        def plane(name):
+            if name in own:
+                return own[name].numpy()
+            o, nb, dt, shape = self._slab_layout[name]
+            return slab_np[o:o + nb].view(_NP_DTYPES[dt]).reshape(shape)
+
+        obs_h, rew_h = obs_t.numpy(), plane("reward")
+        term_h, trunc_h = plane("terminated").astype(bool), plane("truncated").astype(bool)
         dones = term_h | trunc_h
-        n_done = int(self.n_done.item())
-        host = dict(terminated=term_h, truncated=trunc_h, distance=info["distance"].cpu().numpy(),
-                    min_distance=info["min_distance"].cpu().numpy(), fuel=info["fuel"].cpu().numpy(),
-                    flags=info["flags"].cpu().numpy(), t_start=self._t_start, missiles=info["missiles"].cpu().numpy(),
-                    interceptor_pos=info["interceptor_pos"].cpu().numpy(), missile_pos=info["missile_pos"].cpu().numpy(),
-                    steps=info["steps"].cpu().numpy(), radar_quality=self.rc.radar_quality,
+        n_done = int(plane("n_done")[0])
+        host = dict(terminated=term_h, truncated=trunc_h, t_start=self._t_start, radar_quality=self.rc.radar_quality,
                     volley=(bool(self.rc.volley_mode), int(self.rc.volley_size) if self.rc.volley_mode else 1))
-        if "radar_debug" in info:
-            host["radar"] = dict(planes=info["radar_debug"].cpu().numpy(), rc=self.rc,
-                                 beam_width=self.curriculum()["beam_width"])
+        for k in ("distance", "min_distance", "fuel", "flags", "missiles", "interceptor_pos", "missile_pos", "steps"):
+            host[k] = plane(k)
+        if "radar_debug" in self._slab_layout:
+            host["radar"] = dict(planes=plane("radar_debug"), rc=self.rc, beam_width=self.curriculum()["beam_width"])
         done_rows: Dict[int, int] = {}
         if n_done:
             idx = self.done_idx[:n_done].to(self._torch.int64)

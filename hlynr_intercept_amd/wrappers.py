@@ -166,12 +166,9 @@ class _DeviceObsWrapper(_SB3VecEnv):
         return self.reset_torch().cpu().numpy()
 
     def step_async(self, actions):
-        b = self._base
-        a = np.ascontiguousarray(actions, dtype=np.float32)
-        if a.shape != (self.num_envs, _lib.ACT_DIM):
-            raise ValueError(f"actions must have shape ({self.num_envs}, {_lib.ACT_DIM}), got {a.shape}")
-        b._actions_dev.copy_(self._torch.from_numpy(a))
-        self._pending = self.step_torch(b._actions_dev, want_done_list=True)
+        if self._pending is not None:
+            raise RuntimeError("step_async() called twice without step_wait()")
+        self._pending = self.step_torch(self._base._upload_actions(actions), want_done_list=True)
 
     def step_wait(self):
         if self._pending is None:
