@@ -38,7 +38,6 @@ DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
 DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 DEV V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
-DEV V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
 DEV V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
 DEV D3 d3(double x, double y, double z) { return D3{x, y, z}; }
 DEV D3 to_d3(V3 a) { return D3{(double)a.x, (double)a.y, (double)a.z}; }
@@ -49,9 +48,53 @@ DEV D3 operator*(D3 a, double s) { return D3{a.x * s, a.y * s, a.z * s}; }
 DEV double ddot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 DEV double dnorm(D3 a) { return sqrt(ddot(a, a)); }
 
+// Correctly rounded float32 sqrt and division WITHOUT the range handling of the compiler's expansions.
+// sqrt_rn: exact for x = 0, +inf and every x >= 2^-104 (measured: the last mismatch with sqrtf is 0x0b6e9372 = 4.6e-32).  The raw v_sqrt_f32 (1 ulp) plus the two neighbour-residual tests of
+//   the compiler's own sqrtf sequence, minus its denormal pre/post-scaling (5 of 16 instructions).  Every argument on the
+//   step path is a sum of squares of metre / second scale float32 values: exactly 0, or far above that.
+// div_rn: exact whenever neither operand nor the quotient leaves the normal range and b != 0: the compiler's sequence
+//   (reciprocal, one Newton step, quotient, two residual corrections) minus v_div_scale x2 / v_div_fixup and the VCC hazard
+//   of v_div_fmas (3 of 11 instructions + wait states).  Used only where the operands are bounded.
+// tools/micro/rn_check.hip compares both with sqrtf / operator/ (all 2^31 non-negative floats; 2^34 random pairs).
+DEV float sqrt_rn(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float lo = __uint_as_float(__float_as_uint(s) - 1u), hi = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rl = __builtin_fmaf(-lo, s, x), rh = __builtin_fmaf(-hi, s, x);
+    float r = (0.f >= rl) ? lo : s;
+    r = (0.f < rh) ? hi : r;
+    return (x == 0.f || x == __builtin_inff()) ? x : r;
+}
+DEV float div_rn(float a, float b) {
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    const float y = __builtin_fmaf(__builtin_fmaf(-b, y0, 1.0f), y0, y0);
+    const float q0 = a * y;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-b, q0, a), y, q0);
+    return __builtin_fmaf(__builtin_fmaf(-b, q1, a), y, q1);
+}
+
+#ifndef HLX_SHORT_SQRT
+#define HLX_SHORT_SQRT 1
+#endif
+#if HLX_SHORT_SQRT
+#define HLX_SQRTF(x) sqrt_rn(x)
+#else
+#define HLX_SQRTF(x) __builtin_sqrtf(x)
+#endif
+
+#ifndef HLX_SHORT_DIV
+#define HLX_SHORT_DIV 1
+#endif
+#if HLX_SHORT_DIV
+#define HLX_DIVF(a, b) div_rn((a), (b))
+#else
+#define HLX_DIVF(a, b) ((a) / (b))
+#endif
+// vector / norm-like scalar: every caller divides by a guarded norm (> 1e-6) or an O(1) physical scale
+DEV V3 operator/(V3 a, float s) { return V3{HLX_DIVF(a.x, s), HLX_DIVF(a.y, s), HLX_DIVF(a.z, s)}; }
+
 // numpy float32 dot / norm (OpenBLAS sdot): float32 products, float64 accumulation, one rounding
 DEV float sdot3(V3 a, V3 b) { return (float)(((double)(a.x * b.x) + (double)(a.y * b.y)) + (double)(a.z * b.z)); }
-DEV float snorm3(V3 a) { return sqrtf(sdot3(a, a)); }
+DEV float snorm3(V3 a) { return HLX_SQRTF(sdot3(a, a)); }
 DEV V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 // x / c with c a constant whose float64 reciprocal is `inv`
@@ -114,10 +157,10 @@ DEV float fast_asin(float x) {
     p = __builtin_fmaf(ax, p, 0.0889789874f);
     p = __builtin_fmaf(ax, p, -0.2145988016f);
     p = __builtin_fmaf(ax, p, 1.5707963050f);
-    return copysignf(1.5707963267948966f - __builtin_sqrtf(1.0f - ax) * p, x);
+    return copysignf(1.5707963267948966f - HLX_SQRTF(1.0f - ax) * p, x);
 }
 DEV float fdot(V3 a, V3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
-DEV float fnorm(V3 a) { return __builtin_sqrtf(fdot(a, a)); }
+DEV float fnorm(V3 a) { return HLX_SQRTF(fdot(a, a)); }
 
 // ---------------------------------------------------------------------------------------------
 // Counter-based RNG: Philox4x32-10 keyed by the env-set seed; counter = (global env id, vec-step,
@@ -197,8 +240,8 @@ DEV void atmosphere(float alt, float T0, float& rho, float& sos) {
         const float Pb = 5474.790039909648f;      // 22632 * exp(-g*9000/(R*216.65))  (:112)
         P = Pb * expf(-ex / 6000.0f);
     }
-    rho = P / (R * T);                            // :166
-    sos = sqrtf(GAMMA_R * T);                     // :167-169
+    rho = HLX_DIVF(P, R * T);                     // :166
+    sos = HLX_SQRTF(GAMMA_R * T);                     // :167-169
 }
 
 struct DragParams {
@@ -208,15 +251,15 @@ struct DragParams {
 DEV V3 mach_drag_force(V3 v, float rho, float sos, float area, const DragParams& p) {
     float vm = snorm3(v);
     if (vm < 1e-6f) return v3(0.f, 0.f, 0.f);
-    float mach = vm / sos;                                                  // :233-234
+    float mach = HLX_DIVF(vm, sos);                                          // :233-234
     float cd;
     if (mach < p.subsonic) cd = p.base_cd;                                  // :207-209
     else if (mach < p.supersonic) {
-        float frac = (mach - p.subsonic) / p.mach_span;                     // :213-214
+        float frac = HLX_DIVF(mach - p.subsonic, p.mach_span);              // :213-214
         cd = p.base_cd * (1.0f + (p.peak - 1.0f) * frac);                   // :215-216
     } else cd = p.cd_super;                                                 // :220 (python-float product)
     float a = (((0.5f * rho) * (vm * vm)) * cd) * area;                     // :258
-    return V3{(-v.x / vm) * a, (-v.y / vm) * a, (-v.z / vm) * a};           // :262-264
+    return V3{HLX_DIVF(-v.x, vm) * a, HLX_DIVF(-v.y, vm) * a, HLX_DIVF(-v.z, vm) * a};   // :262-264
 }
 // the same with a float64 air-relative velocity (Mach model on, simple float64 wind): generic kernel only
 DEV D3 mach_drag_force64(D3 v, float rho, float sos, double area, const DragParams& p) {

@@ -341,9 +341,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
             }
             if (fuel <= 0.f) { at = at * 0.f; clamped = true; }                      // core.py:1080-1083
             float am = snorm3(at);
-            if (am > 50.f) { at = at * (50.f / am); clamped = true; }                // core.py:1086-1090
+            if (am > 50.f) { at = at * HLX_DIVF(50.f, am); clamped = true; }                // core.py:1086-1090
             float gm = snorm3(aw);
-            if (gm > 5.f) { aw = aw * (5.f / gm); clamped = true; }                  // core.py:1094-1098
+            if (gm > 5.f) { aw = aw * HLX_DIVF(5.f, gm); clamped = true; }                  // core.py:1094-1098
 
             // Is the reference's wind a float64 array at this point?  Simple wind: float32 copy of
             // base_wind after reset, float64 from the first update on (environment.py:542,1127-1129).
@@ -400,9 +400,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
                 if (angle > 1e-6f) {
                     float half = angle * 0.5f;                                      // angle / 2 (exact)
                     float ch = (float)cos_small((double)half), sh = (float)sin_small((double)half);
-                    Quat r = quat_mul(Quat{ch, (ang.x / wn) * sh, (ang.y / wn) * sh, (ang.z / wn) * sh}, q);
-                    float nq = sqrtf((float)((((double)(r.w * r.w) + (double)(r.x * r.x)) + (double)(r.y * r.y)) + (double)(r.z * r.z)));
-                    q = Quat{r.w / nq, r.x / nq, r.y / nq, r.z / nq};
+                    Quat r = quat_mul(Quat{ch, HLX_DIVF(ang.x, wn) * sh, HLX_DIVF(ang.y, wn) * sh, HLX_DIVF(ang.z, wn) * sh}, q);
+                    float nq = HLX_SQRTF((float)((((double)(r.w * r.w) + (double)(r.x * r.x)) + (double)(r.y * r.y)) + (double)(r.z * r.z)));
+                    q = Quat{HLX_DIVF(r.w, nq), HLX_DIVF(r.x, nq), HLX_DIVF(r.y, nq), HLX_DIVF(r.z, nq)};
                 }
             }
             STAMP(4);   // interceptor integrated
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
             if (HAS(HLX_F_PROX_FUZE) && min_distance < HOT(c.kill_radius)) { fuze = true; intercepted = true; } // :715-717
             const bool ground = mpos.z <= 0.f;
             const float gdx = mpos.x - HOT(c.target[0]), gdy = mpos.y - HOT(c.target[1]);
-            const bool near_target = sqrtf((float)((double)(gdx * gdx) + (double)(gdy * gdy))) < 500.f;
+            const bool near_target = HLX_SQRTF((float)((double)(gdx * gdx) + (double)(gdy * gdy))) < 500.f;
             if (HAS(HLX_F_VOLLEY)) {                                                // :724-748
                 bool all_inactive = true;
 #pragma unroll
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
                         if (vp[k].z <= 0.f) {                                       // on the ground: neutralised
                             vact[k] = false;
                             const float gx = vp[k].x - HOT(c.target[0]), gy = vp[k].y - HOT(c.target[1]);
-                            if (sqrtf((float)((double)(gx * gx) + (double)(gy * gy))) < 500.f) hit_target = true;
+                            if (HLX_SQRTF((float)((double)(gx * gx) + (double)(gy * gy))) < 500.f) hit_target = true;
                         }
                         if (vact[k]) all_inactive = false;
                     }
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
                     float md = min_distance;
                     if (crossed) {
                         reward = 3000.f;
-                        if (md < HOT(cur.radius)) reward = reward + ((HOT(cur.radius) - md) / HOT(cur.radius)) * 1000.f;
+                        if (md < HOT(cur.radius)) reward = reward + HLX_DIVF(HOT(cur.radius) - md, HOT(cur.radius)) * 1000.f;
                         reward = reward + expf(divc(-md, 1.0 / 25.0)) * 500.f;
                         reward = reward + expf(divc(-md, 1.0 / 10.0)) * 1000.f;
                         reward = reward + expf(divc(-md, 1.0 / 3.0)) * 500.f;
@@ -945,7 +945,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
                         kf_init = true;
                     } else {                                                        // core.py:98-116 on the 2x2 blocks
                         const bool y64 = m64 || kf_x64;
-                        const float sinv = 1.0f / (p_pp + 400.f);
+                        const float sinv = HLX_DIVF(1.0f, p_pp + 400.f);
                         const float kp = p_pp * sinv, kv = p_vp * sinv;
                         D3 y = d3(rr(z.x - kxp.x, y64), rr(z.y - kxp.y, y64), rr(z.z - kxp.z, y64));
                         kxp = d3(rr(kxp.x + rr((double)kp * y.x, y64), y64), rr(kxp.y + rr((double)kp * y.y, y64), y64),
