@@ -1,0 +1,46 @@
+"""The in-kernel random number generator is Philox4x32-10 keyed as DESIGN.md 5 says: key = the env-set seed, counter =
+(global env id lo, hi, vec-step lo, (vec-step hi << 8) | stream).  CPU: the plain-Python restatement reproduces the
+published known-answer vectors.  GPU: the uniforms `hlx_fill_noise` exports are exactly that function's words."""
+import numpy as np
+import pytest
+
+from tests.philox_ref import philox4x32, u01
+
+# Random123 kat_vectors, "philox4x32 10": counter, key -> output
+KAT = [
+    ((0x00000000,) * 4, (0x00000000,) * 2, (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+    ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2, (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+    ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
+     (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)),
+]
+
+
+@pytest.mark.parametrize("ctr,key,out", KAT)
+def test_reference_implementation_known_answers(ctr, key, out):
+    assert philox4x32(ctr, key) == out
+
+
+@pytest.mark.gpu
+def test_device_uniforms_are_philox4x32_10_words():
+    from hlynr_intercept_amd.scenarios import scenario_config
+    from hlynr_intercept_amd.vec_env import HlynrVecEnv
+
+    seed, offset, n = 0x1234_5678_9ABC_DEF0, (1 << 33) + 12345, 130
+    env = HlynrVecEnv(scenario_config("medium", "base"), num_envs=n, seed=seed, env_id_offset=offset)
+    env.reset()
+    env.step(np.zeros((n, 6), np.float32))
+    key = (seed & 0xFFFFFFFF, seed >> 32)
+    for for_reset in (False, True):
+        sn, rn = (x.cpu().numpy() for x in env.fill_noise(for_reset=for_reset))
+        t = int(env._lib.hlx_vec_steps(env._h)) + (0 if for_reset else 1)
+        for i in (0, 1, 63, 64, 129):
+            gid = offset + i
+
+            def words(stream):
+                return philox4x32((gid & 0xFFFFFFFF, gid >> 32, t & 0xFFFFFFFF, ((t >> 32) << 8) | stream), key)
+
+            x = words(0)                                   # RS_STEP_U: onboard, ground, datalink, gust uniforms
+            assert [sn[11, i], sn[12, i], sn[19, i], sn[6, i]] == [u01(w) for w in x], (for_reset, i)
+            r0, r1, r2 = words(8), words(9), words(10)     # RS_RESET_U0..2: the ten spawn uniforms
+            assert list(rn[0:10, i]) == [u01(w) for w in (*r0, *r1, *r2[:2])], (for_reset, i)
+    env.close()
