@@ -113,7 +113,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
     float4* __restrict__ arena, const KParams* __restrict__ P, const float* __restrict__ actions0,
     const unsigned long long t0, const unsigned long long seed, const long long env_offset, const int n,
     const uint32_t slots,   // bits 0-3 ground-ring read slot, 4-7 ground-ring write slot, 8-11 onboard-ring write slot,
-                            // 12-15 ground-ring planes (delay+1, 0 = no ring), 16-19 onboard-ring planes (0 = no ring)
+                            // 12-15 ground-ring planes (delay+1, 0 = no ring), 16-19 onboard-ring planes (0 = no ring),
+                            // bit 20: some hlx_info_soa plane is wanted
     // ---- ordinary kernarg tail (one scalar load, issued at entry, first needed when results are stored)
     float* __restrict__ obs_out0, float* __restrict__ reward_out0, uint8_t* __restrict__ term_out0,
     uint8_t* __restrict__ trunc_out0,
@@ -615,6 +616,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
             reward_out[i] = reward;
             term_out[i] = terminated ? 1 : 0;
             trunc_out[i] = truncated ? 1 : 0;
+            if (slots & (1u << 20)) {   // some hlx_info_soa plane is wanted (one SGPR test instead of nine pointer fetches)
             if (HOT(opt.info.distance)) HOT(opt.info.distance)[i] = distance;
             if (HOT(opt.info.min_distance)) HOT(opt.info.min_distance)[i] = min_distance;
             if (HOT(opt.info.fuel)) HOT(opt.info.fuel)[i] = fuel;
@@ -635,6 +637,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
                     for (int k = 0; k < HLX_MAX_VOLLEY; ++k) remaining += (k < VK && vact[k]) ? 1 : 0;
                 }
                 HOT(opt.info.missiles)[i] = (uint8_t)(got | (remaining << 4));
+            }
             }
         }
         // Kalman / ring registers become visible here (their loads were issued last, at kernel entry)
@@ -907,7 +910,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
                 }
                 if (pass == 0) {
                     det_bits = (d_on_det ? 32u : 0u) | (d_g_det ? 64u : 0u);
-                    if (HAS(HLX_F_RADAR_DEBUG) && HOT(opt.info.radar_debug)) {     // what info['radar_debug'] (core.py:650-683) cannot rebuild from positions
+                    if (HAS(HLX_F_RADAR_DEBUG) && (slots & (1u << 20)) && HOT(opt.info.radar_debug)) {     // what info['radar_debug'] (core.py:650-683) cannot rebuild from positions
                         float* rd = HOT(opt.info.radar_debug) + i;
                         rd[0] = q.w; rd[N] = q.x; rd[2 * N] = q.y; rd[3 * N] = q.z;
                         rd[4 * N] = d_gq;
@@ -1122,7 +1125,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
             }
         }
         if (MODE == 0) {
-            if (HOT(opt.info.flags))
+            if ((slots & (1u << 20)) && HOT(opt.info.flags))
                 HOT(opt.info.flags)[i] = (uint8_t)((intercepted ? 1u : 0u) | (hit_target ? 2u : 0u) | (fuze ? 4u : 0u) |
                                             (clamped ? 8u : 0u) | (crossed ? 16u : 0u) | det_bits);
         }
