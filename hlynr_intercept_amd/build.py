@@ -32,11 +32,21 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-Wno-unused-value",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    tmp = LIB + ".unverified"
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-Wno-unused-value",
+           "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
+    # the constants of the step kernel are fetched across lanes (v_readlane): a register-allocator spill of those two
+    # VGPRs would silently corrupt them, so the code object is inspected before the library is put in place
+    from . import hotcheck
+    try:
+        hotcheck.verify(tmp)
+    except Exception:
+        os.replace(tmp, LIB + ".rejected")
+        raise
+    os.replace(tmp, LIB)
     return LIB
 
 
@@ -44,7 +54,7 @@ def build_stamps(level: int = 1) -> str:
     """Diagnostic build with s_memtime stamps (tools/diag_stamps.py); never used by the product path."""
     out = os.path.join(_HERE, "libhlx_stamps.so")
     subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                           "-mllvm", "-amdgpu-kernarg-preload-count=16", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-Wno-unused-value", f"-DHLX_STAMPS={level}", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES],
+                           "-mllvm", "-amdgpu-kernarg-preload-count=16", "-Wno-unused-value", f"-DHLX_STAMPS={level}", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES],
                           cwd=CSRC)
     return out
 

@@ -161,6 +161,8 @@ DEV float fast_asin(float x) {
 }
 DEV float fdot(V3 a, V3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
 DEV float fnorm(V3 a) { return HLX_SQRTF(fdot(a, a)); }
+// for pure outputs (observation entries, data-link / fusion scores): the raw 1-ulp v_sqrt_f32
+DEV float fnorm_out(V3 a) { return __builtin_amdgcn_sqrtf(fdot(a, a)); }
 
 // ---------------------------------------------------------------------------------------------
 // Counter-based RNG: Philox4x32-10 keyed by the env-set seed; counter = (global env id, vec-step,
@@ -290,15 +292,15 @@ struct Quat {
 };
 DEV V3 forward_vec(Quat q) {   // core.py:1143-1152 (feeds a threshold compare and pure outputs: fast float32)
     V3 f = v3(2.f * (q.x * q.z + q.w * q.y), 2.f * (q.y * q.z - q.w * q.x), 1.f - 2.f * (q.x * q.x + q.y * q.y));
-    return f * __builtin_amdgcn_rcpf(fnorm(f) + 1e-6f);
+    return f * __builtin_amdgcn_rcpf(fnorm_out(f) + 1e-6f);
 }
 DEV V3 right_vec(Quat q) {     // core.py:1155-1164
     V3 f = v3(1.f - 2.f * (q.y * q.y + q.z * q.z), 2.f * (q.x * q.y + q.w * q.z), 2.f * (q.x * q.z - q.w * q.y));
-    return f * __builtin_amdgcn_rcpf(fnorm(f) + 1e-6f);
+    return f * __builtin_amdgcn_rcpf(fnorm_out(f) + 1e-6f);
 }
 DEV V3 up_vec(Quat q) {        // core.py:1167-1176
     V3 f = v3(2.f * (q.x * q.y - q.w * q.z), 1.f - 2.f * (q.x * q.x + q.z * q.z), 2.f * (q.y * q.z + q.w * q.x));
-    return f * __builtin_amdgcn_rcpf(fnorm(f) + 1e-6f);
+    return f * __builtin_amdgcn_rcpf(fnorm_out(f) + 1e-6f);
 }
 DEV Quat quat_mul(Quat a, Quat b) {  // environment.py:1322-1331 (left-to-right float32 sums)
     return Quat{((a.w * b.w - a.x * b.x) - a.y * b.y) - a.z * b.z, ((a.w * b.x + a.x * b.w) + a.y * b.z) - a.z * b.y,

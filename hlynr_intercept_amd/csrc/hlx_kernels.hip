@@ -104,10 +104,15 @@ template <typename P> struct HotRd<P*> { static DEV P* get(uint32_t w0, uint32_t
 // loaded as a second batch after the Philox block instead of at kernel entry (see below; a run-time switch was tried
 // and lost both ways -- the optimiser merges the two load sites).
 template <uint32_t SPEC, int MODE /*0 = step, 1 = reset-only*/, bool NOISE, bool PERSIST = false, bool LATE = false>
+// The parity (NOISE) and reset-only (MODE 1) instantiations never run at a size where occupancy matters: they get the
+// whole register file, hence no scratch spills (see tools/check_hot_words.py for why a spilled hot word is fatal).
+#ifndef HLX_WAVES_PER_EU
+#define HLX_WAVES_PER_EU(noise, mode) (((noise) || (mode) == 1) ? 1 : 2)
+#endif
 // waves_per_eu(2): keep every instantiation within 256 VGPRs so that two waves fit on a SIMD.  The single-step kernels
 // are there anyway (183); the fused-rollout ones spill 4-19 dwords to scratch for it and run 1.5x faster once the batch
 // gives a SIMD two waves (1 M envs: 107 -> 72 us per step, 1.46e10 env-steps/s), unchanged below that.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hlx_env_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PER_EU(NOISE, MODE)))) void hlx_env_kernel(
     // ---- 14 dwords preloaded into SGPRs by the dispatcher: everything needed to issue the state, action and
     //      ring loads and to run the Philox block without waiting for memory
     float4* __restrict__ arena, const KParams* __restrict__ P, const float* __restrict__ actions0,
@@ -891,10 +896,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
                 // ---- datalink (core.py:440-474)
                 float datalink = 0.f;
                 if (HAS(HLX_F_GROUND)) {
-                    float lr = fnorm(ipos - gp);
+                    float lr = fnorm_out(ipos - gp);
                     if (!(lr > HOT(c.max_datalink)) && !(n_dl < HOT(c.packet_loss))) {
                         float x = lr * HOT(c.inv_max_datalink);
-                        float vr = fnorm(ivel) * 0.001f;
+                        float vr = fnorm_out(ivel) * 0.001f;
                         float dop = (0.3f < vr) ? (float)(1.0 - 0.3) : (1.0f - vr);
                         datalink = clampf(((1.0f - x * x) * dop) * 0.95f, 0.f, 1.f);
                     }
@@ -905,7 +910,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
                 else if (!d_g_det) fusion = (float)(HOT(c.radar_quality64) * 0.5);
                 else if (!d_on_det) fusion = d_gq * 0.6f;
                 else {
-                    float agree = 1.0f - fminf(fnorm(d_on - d_gp) * 0.005f, 1.0f);
+                    float agree = 1.0f - fminf(fnorm_out(d_on - d_gp) * 0.005f, 1.0f);
                     fusion = clampf((float)(0.35 * HOT(c.radar_quality64)) + 0.50f * d_gq + 0.15f * agree, 0.f, 1.f);
                 }
                 if (pass == 0) {
@@ -983,7 +988,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
                     const D3 frp64 = d3(rr(kxp.x - (double)ipos.x, kf_x64), rr(kxp.y - (double)ipos.y, kf_x64), rr(kxp.z - (double)ipos.z, kf_x64));
                     const D3 frv64 = d3(rr(kxv.x - (double)ivel.x, kf_x64), rr(kxv.y - (double)ivel.y, kf_x64), rr(kxv.z - (double)ivel.z, kf_x64));
                     const V3 frp = to_v3(frp64), frv = to_v3(frv64);
-                    const float rrange = fnorm(frp);
+                    const float rrange = fnorm_out(frp);
                     const float closing = -fdiv(fdot(frp, frv), rrange + 1e-6f);    // :786
                     if (HAS(HLX_F_OBS_LOS)) {                                       // :791-868
                         row[0] = clampf(rrange * inv_mr, 0.f, 1.f);
@@ -994,11 +999,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
                         los_basis(lu, h, v);
                         row[2] = clampf(fdot(rate, h) * 2.0f, -1.f, 1.f);           // :844-845 (/0.5)
                         row[3] = clampf(fdot(rate, v) * 2.0f, -1.f, 1.f);
-                        float ivm = fnorm(ivel);
+                        float ivm = fnorm_out(ivel);
                         row[4] = (ivm > 1e-6f) ? fdiv(fdot(ivel, lu), ivm) : 0.f;    // :852-858
                         V3 tv = to_v3(d3(rr(frv64.x + (double)ivel.x, kf_x64), rr(frv64.y + (double)ivel.y, kf_x64),
                                          rr(frv64.z + (double)ivel.z, kf_x64)));                // :861
-                        float tvm = fnorm(tv);
+                        float tvm = fnorm_out(tv);
                         row[5] = (tvm > 1e-6f) ? -fdiv(fdot(tv, lu), tvm) : 0.f;
                         row[6] = clampf(ivm * inv_mv, 0.f, 1.f);                    // :924-925
                         row[7] = clampf(fdot(ivel, h) * inv_mv, -1.f, 1.f);         // :948-953
@@ -1026,7 +1031,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
 #pragma unroll
                     for (int k = 0; k < 6; ++k) row[k] = -2.0f;
                     row[13] = -1.0f; row[14] = 0.f; row[15] = 0.f; row[16] = 0.f;
-                    if (HAS(HLX_F_OBS_LOS)) { row[6] = clampf(fnorm(ivel) * inv_mv, 0.f, 1.f); row[7] = 0.f; row[8] = 0.f; }
+                    if (HAS(HLX_F_OBS_LOS)) { row[6] = clampf(fnorm_out(ivel) * inv_mv, 0.f, 1.f); row[7] = 0.f; row[8] = 0.f; }
                 }
                 if (HAS(HLX_F_OBS_BODY)) {                                          // :959-962
                     V3 r = right_vec(q), up = up_vec(q);
@@ -1047,11 +1052,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hl
                 row[12] = clampf(fuel * 0.01f, 0.f, 1.f);                           // :977
                 if (d_g_det && datalink > 0.1f) {                                   // :980-1018
                     if (HAS(HLX_F_OBS_LOS)) {
-                        float gr = fnorm(d_gp);
+                        float gr = fnorm_out(d_gp);
                         float gc = -fdiv(fdot(d_gp, d_gv), gr + 1e-6f);
                         row[17] = clampf(gr * inv_mr, 0.f, 1.f);
                         row[18] = clampf(gc * inv_mv, -1.f, 1.f);
-                        row[19] = (gr > 1e-6f) ? clampf(fdiv(fnorm(d_gv - d_gp * fdiv(gc, gr)), gr) * 2.0f, 0.f, 1.f) : 0.f;
+                        row[19] = (gr > 1e-6f) ? clampf(fdiv(fnorm_out(d_gv - d_gp * fdiv(gc, gr)), gr) * 2.0f, 0.f, 1.f) : 0.f;
                         row[20] = 0.f; row[21] = 0.f; row[22] = 0.f;
                     } else if (HAS(HLX_F_OBS_BODY)) {
                         V3 r = right_vec(q), up = up_vec(q);

@@ -1,0 +1,116 @@
+"""Build-time guard for the hot-constant scheme of the step kernel.
+
+Every constant of the 512-byte parameter block lives in ONE lane of two VGPRs per wave ("hot words") and is fetched
+with v_readlane at its use site.  That is only correct while those two VGPRs hold all 64 lanes: a register-allocator
+spill reload (scratch_load) or live-range-split copy (v_mov) of a hot word inside divergent control flow restores only
+the ACTIVE lanes, and a later v_readlane of an inactive lane would return garbage.  (Seen once: the parity-only NOISE
+instantiation of the generic variant, at 256 VGPRs with 440 B of scratch, lost `on_rel` that way.)
+
+This script disassembles the gfx950 code object inside the BUILT library (what ships) and checks, for every
+hlx_env_kernel instantiation, each VGPR that is a v_readlane source and never a v_writelane destination (those are the
+compiler's own SGPR-spill registers, which it saves in whole-wave mode): between the vector load that fills it and its
+last v_readlane it must never be the destination of a scratch_load (spill reload: FAIL).  Other writes in that window
+(v_mov save/restore pairs of a live-range split around a region that borrows the register) are listed as information:
+they execute under the same EXEC mask on both sides and leave the lanes that did not take part untouched.
+Usage: python -m hlynr_intercept_amd.hotcheck [libhlx.so | listing.s]; exit code 1 on a spill reload.
+hlynr_intercept_amd/build.py runs the same check after every build (`verify`)."""
+import collections
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+LLVM_BIN = os.environ.get("HLX_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+
+
+def listing(path=None):
+    """Assembly text of the kernels: a `hipcc -S` listing as is, or the disassembly of the library's gfx950 code object."""
+    path = path or os.path.join(HERE, "libhlx.so")
+    if path.endswith(".s"):
+        return open(path).read()
+    tmp = tempfile.mkdtemp()
+    fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "gfx950.co")
+    subprocess.run([os.path.join(LLVM_BIN, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, path], check=True)
+    subprocess.run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                    "--input=" + fat, "--output=" + co, "--unbundle"], check=True)
+    return subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", "--no-show-raw-insn", co], check=True,
+                          capture_output=True, text=True).stdout
+
+
+def regs(operand):
+    """'v12' -> [12]; 'v[4:7]' -> [4, 5, 6, 7]."""
+    m = re.fullmatch(r"v(\d+)", operand)
+    if m:
+        return [int(m.group(1))]
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", operand)
+    return list(range(int(m.group(1)), int(m.group(2)) + 1)) if m else []
+
+
+def check(text):
+    """-> (kernels seen, [(kernel, reg, {opcode: count})] spill reloads, same for other in-window writes)."""
+    lines = [l.split("//")[0].rstrip() for l in text.split("\n")]
+    label = re.compile(r"^(?:[0-9a-f]+ <)?(_ZN\S*hlx_env_kernel[^>:\s]*)>?:")
+    any_label = re.compile(r"^(?:[0-9a-f]+ <\S+>:|\S+:\s*(;.*)?$)")
+    starts = [i for i, l in enumerate(lines) if label.match(l)]
+    fail, info = [], []
+    for i in starts:
+        name = label.match(lines[i]).group(1)
+        end = next((j for j in range(i + 1, len(lines))
+                    if lines[j].strip().startswith(".end_amdhsa_kernel") or (any_label.match(lines[j]) and "hlx_env_kernel" in lines[j])
+                    or re.match(r"^[0-9a-f]+ <_Z", lines[j])), len(lines))
+        readlane_src, writelane_dst = set(), set()
+        first_read, last_read = {}, {}
+        writes = collections.defaultdict(list)          # reg -> [(position, opcode)]
+        for pos, t in enumerate(x.strip() for x in lines[i + 1:end]):
+            if not t or t.startswith((".", ";")):
+                continue
+            parts = t.replace(",", " ").split()
+            op = parts[0]
+            if op == "v_readlane_b32":
+                for r in regs(parts[2]):
+                    readlane_src.add(r)
+                    first_read.setdefault(r, pos)
+                    last_read[r] = pos
+            if op == "v_writelane_b32":
+                writelane_dst.update(regs(parts[1]))
+            if op.startswith(("v_", "global_load", "buffer_load", "scratch_load", "ds_read", "ds_bpermute", "flat_load")) and \
+                    not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")) and len(parts) > 1:
+                for r in regs(parts[1]):
+                    writes[r].append((pos, op))
+        is_load = lambda op: op.startswith(("global_load", "buffer_load"))       # noqa: E731
+        for r in sorted(readlane_src - writelane_dst):
+            loads = [pos for pos, op in writes[r] if is_load(op) and pos < first_read[r]]
+            if not loads:
+                continue        # not a hot word: a value made uniform some other way (done-list compaction)
+            window = [op for pos, op in writes[r] if max(loads) < pos < last_read[r] and not is_load(op)]
+            reloads = collections.Counter(op for op in window if op.startswith("scratch_load"))
+            other = collections.Counter(op for op in window if not op.startswith("scratch_load"))
+            if reloads:
+                fail.append((name, f"v{r}", dict(reloads)))
+            if other:
+                info.append((name, f"v{r}", dict(other)))
+    return len(starts), fail, info
+
+
+def verify(path=None):
+    """Raise if the library at `path` (default: the in-tree libhlx.so) reloads a hot word from scratch."""
+    n, fail, _ = check(listing(path))
+    if n == 0:
+        raise RuntimeError("hotcheck: no hlx_env_kernel instantiation found in the code object")
+    if fail:
+        raise RuntimeError("hotcheck: the register allocator spilled a hot-constant register (v_readlane would read "
+                           "stale lanes): " + "; ".join(f"{k[:60]}... {r} {ops}" for k, r, ops in fail))
+    return n
+
+
+if __name__ == "__main__":
+    n, fail, info = check(listing(sys.argv[1] if len(sys.argv) > 1 else None))
+    print(f"{n} hlx_env_kernel instantiations checked: {len(fail)} hot-word spill reloads, {len(info)} split copies")
+    for tag, rows in (("SPILL RELOAD", fail), ("split copy", info)):
+        for name, r, ops in rows:
+            print(f"  {tag}: {name[:72]}... {r} written by {ops}")
+    sys.exit(1 if fail or n == 0 else 0)

@@ -1,0 +1,32 @@
+"""The shipped code object must never reload a hot-constant register from scratch (hlynr_intercept_amd/hotcheck.py:
+a spill reload under a partial EXEC mask leaves stale lanes that a later v_readlane would hand out as a constant)."""
+import os
+
+from hlynr_intercept_amd import build, hotcheck
+
+SPILLED = """
+_ZN12_GLOBAL__N_114hlx_env_kernelILj1ELi0ELb0EEEvv:
+\tglobal_load_dword v5, v1, s[4:5]
+\tv_readlane_b32 s0, v5, 3
+\tscratch_store_dword off, v5, off offset:4
+\tv_mov_b32_e32 v5, 0
+\tscratch_load_dword v5, off, off offset:4
+\tv_readlane_b32 s1, v5, 7
+\tv_writelane_b32 v9, s3, 0
+\tv_readlane_b32 s3, v9, 0
+\t.end_amdhsa_kernel
+"""
+
+
+def test_checker_flags_a_spilled_hot_word_and_ignores_sgpr_spill_registers():
+    n, fail, info = hotcheck.check(SPILLED)
+    assert n == 1 and [(r, ops) for _, r, ops in fail] == [("v5", {"scratch_load_dword": 1})]
+    assert [(r, ops) for _, r, ops in info] == [("v5", {"v_mov_b32_e32": 1})]
+    n, fail, info = hotcheck.check(SPILLED.replace("\tscratch_load_dword v5, off, off offset:4\n", ""))
+    assert n == 1 and not fail
+
+
+def test_built_library_keeps_hot_words_in_registers():
+    lib = build.build()
+    assert os.path.exists(lib)
+    assert hotcheck.verify(lib) >= 20          # every hlx_env_kernel instantiation of the product library
