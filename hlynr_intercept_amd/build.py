@@ -33,7 +33,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     tmp = LIB + ".unverified"
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-Wno-unused-value",
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-Wno-unused-value",
            "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
@@ -54,7 +54,7 @@ def build_stamps(level: int = 1) -> str:
     """Diagnostic build with s_memtime stamps (tools/diag_stamps.py); never used by the product path."""
     out = os.path.join(_HERE, "libhlx_stamps.so")
     subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                           "-mllvm", "-amdgpu-kernarg-preload-count=16", "-Wno-unused-value", f"-DHLX_STAMPS={level}", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES],
+                           "-mllvm", "-amdgpu-kernarg-preload-count=16", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-Wno-unused-value", f"-DHLX_STAMPS={level}", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES],
                           cwd=CSRC)
     return out
 

@@ -2,4 +2,4 @@
 # tools/ab_build.sh NAME "-DFOO=1 -DBAR=0"  -> hlynr_intercept_amd/libhlx_NAME.so (A/B experiments)
 set -e
 cd "$(dirname "$0")/../hlynr_intercept_amd/csrc"
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -mllvm -amdgpu-kernarg-preload-count=16 -Wno-unused-value $2 -o ../libhlx_$1.so hlx_kernels.hip
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -mllvm -amdgpu-kernarg-preload-count=16 -mllvm -amdgpu-sched-strategy=max-ilp -Wno-unused-value $2 -o ../libhlx_$1.so hlx_kernels.hip

@@ -1,6 +1,6 @@
 """Static instruction counts per kernel section: compile with -DHLX_MARKS -S and split the listing of one kernel at the
 `; HLXMARK k` comments the STAMP points leave behind.
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -amdgpu-kernarg-preload-count=16 -DHLX_MARKS -S \
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -amdgpu-kernarg-preload-count=16 -mllvm -amdgpu-sched-strategy=max-ilp -DHLX_MARKS -S \
         --cuda-device-only -o /tmp/marks.s hlynr_intercept_amd/csrc/hlx_kernels.hip
   python tools/isa_sections.py /tmp/marks.s 'ILj608ELi0ELb0ELb0ELb1'"""
 import collections, re, sys
