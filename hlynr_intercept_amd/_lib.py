@@ -50,7 +50,7 @@ class HlxInfoSoa(C.Structure):
     _fields_ = [("distance", C.c_void_p), ("min_distance", C.c_void_p), ("fuel", C.c_void_p), ("flags", C.c_void_p),
                 ("episode_return", C.c_void_p), ("episode_length", C.c_void_p), ("missiles", C.c_void_p),
                 ("interceptor_pos", C.c_void_p), ("missile_pos", C.c_void_p), ("steps", C.c_void_p),
-                ("radar_debug", C.c_void_p)]
+                ("missile_min_distances", C.c_void_p), ("radar_debug", C.c_void_p)]
 
 
 class HlxEnvState(C.Structure):

@@ -643,6 +643,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 }
                 HOT(opt.info.missiles)[i] = (uint8_t)(got | (remaining << 4));
             }
+            if (HAS(HLX_F_VOLLEY) && HOT(opt.info.missile_min_distances)) {               // :848
+                float* md = HOT(opt.info.missile_min_distances) + i;
+#pragma unroll
+                for (int k = 0; k < HLX_MAX_VOLLEY; ++k) if (k < VK) md[(size_t)k * (size_t)n] = vmin[k];
+            }
             }
         }
         // Kalman / ring registers become visible here (their loads were issued last, at kernel entry)

@@ -110,6 +110,9 @@ class LazyInfos(Sequence):
             "interceptor_pos": h["interceptor_pos"][:, i].copy(), "missile_pos": h["missile_pos"][:, i].copy(),
             "steps": int(h["steps"][i]), "fuel_used": float(100.0 - h["fuel"][i]),
             "radar_quality": float(h["radar_quality"]) if flags & 32 else 0.0,
+            # environment.py:848: per-missile closest approach in volley mode, [distance] otherwise
+            "missile_min_distances": (h["missile_min_distances"][:h["volley"][1], i].tolist() if "missile_min_distances" in h
+                                      else [float(h["distance"][i])]),
         }
         row = self._done.get(i)
         rd = h.get("radar")
@@ -205,6 +208,8 @@ class HlynrVecEnv(_SB3VecEnv):
         spec = [("reward", f32, (n,)), ("terminated", u8, (n,)), ("truncated", u8, (n,)), ("n_done", i32, (1,)),
                 ("distance", f32, (n,)), ("min_distance", f32, (n,)), ("fuel", f32, (n,)), ("flags", u8, (n,)),
                 ("missiles", u8, (n,)), ("interceptor_pos", f32, (3, n)), ("missile_pos", f32, (3, n)), ("steps", i32, (n,))]
+        if self.rc.volley_mode:
+            spec.append(("missile_min_distances", f32, (_lib.MAX_VOLLEY, n)))
         if radar_debug:
             spec.append(("radar_debug", f32, (8, n)))
         self._slab_layout, off = {}, 0
@@ -222,11 +227,14 @@ class HlynrVecEnv(_SB3VecEnv):
                          episode_length=torch.zeros(n, dtype=torch.int32, device=dev),
                          missiles=v["missiles"], interceptor_pos=v["interceptor_pos"], missile_pos=v["missile_pos"],
                          steps=v["steps"])
+        if self.rc.volley_mode:
+            self.info["missile_min_distances"] = v["missile_min_distances"]
         if radar_debug:
             self.info["radar_debug"] = v["radar_debug"]
         self._info_soa = _lib.HlxInfoSoa(*(self.info[k].data_ptr() for k in
                                            ("distance", "min_distance", "fuel", "flags", "episode_return",
                                             "episode_length", "missiles", "interceptor_pos", "missile_pos", "steps")),
+                                         self.info["missile_min_distances"].data_ptr() if self.rc.volley_mode else None,
                                          self.info["radar_debug"].data_ptr() if radar_debug else None)
         self._actions_dev = torch.zeros((n, _lib.ACT_DIM), dtype=torch.float32, device=dev)
         self._actions_pin = torch.zeros((n, _lib.ACT_DIM), dtype=torch.float32, pin_memory=True)
@@ -371,6 +379,8 @@ class HlynrVecEnv(_SB3VecEnv):
                     volley=(bool(self.rc.volley_mode), int(self.rc.volley_size) if self.rc.volley_mode else 1))
         for k in ("distance", "min_distance", "fuel", "flags", "missiles", "interceptor_pos", "missile_pos", "steps"):
             host[k] = plane(k)
+        if "missile_min_distances" in self._slab_layout:
+            host["missile_min_distances"] = plane("missile_min_distances")
         if "radar_debug" in self._slab_layout:
             host["radar"] = dict(planes=plane("radar_debug"), rc=self.rc, beam_width=self.curriculum()["beam_width"])
         done_rows: Dict[int, int] = {}

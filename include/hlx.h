@@ -130,6 +130,10 @@ typedef struct hlx_info_soa {
                                      train_hrl_pretrain.py:180-198, inference.py:535-560) */
     float *missile_pos;       /* [3][N] plane-major: info['missile_pos'] = the priority missile (environment.py:836) */
     int32_t *steps;           /* [N] info['steps'] (environment.py:838) */
+    float *missile_min_distances; /* [HLX_MAX_VOLLEY][N] plane-major, volley mode only: info['missile_min_distances']
+                                     (environment.py:848) -- the closest approach to each missile of the volley so far;
+                                     planes >= volley_size are not written.  (Outside volley mode the reference's value is
+                                     [distance].) */
     float *radar_debug;       /* [8][N] plane-major, what info['radar_debug'] (environment.py:842, core.py:650-683) needs
                                      beyond the positions: planes 0-3 interceptor quaternion w,x,y,z; 4 delayed ground-radar
                                      quality; 5 an int32 bit pattern: bits0-2 the delayed onboard 'detection_reason'

@@ -193,6 +193,9 @@ def _replay_fixture(name, radar):
         if "missiles_intercepted" in fx:   # volley: info['missiles_intercepted'] / ['missiles_remaining']
             m = info["missiles"].cpu().numpy()
             assert np.all((m & 15) == int(fx["missiles_intercepted"][t])) and np.all((m >> 4) == int(fx["missiles_remaining"][t])), (t, m)
+            K = int(fx["volley_size"])      # info['missile_min_distances'] (environment.py:848)
+            md = info["missile_min_distances"].cpu().numpy()[:K, 0]
+            assert np.max(_rel(md, fx["missile_min_distances"][t])) <= 2 * RTOL, (t, md, fx["missile_min_distances"][t])
         step_obs = info["terminal_observation"].cpu().numpy() if fx["did_reset"][t] else obs_h
         worst["obs"] = max(worst["obs"], float(np.max(np.abs(step_obs - fx["obs"][t][None]))))
         rew_errs.append(float(np.max(_rel(rew_h, fx["reward"][t]))))

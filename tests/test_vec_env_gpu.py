@@ -54,9 +54,11 @@ def test_info_keys_the_reference_callers_read():
     info = infos[3]
     for key in ("distance", "intercepted", "missile_hit_target", "fuel_remaining", "fuel_used", "clamped", "interceptor_pos",
                 "missile_pos", "steps", "radar_detected", "radar_quality", "min_distance", "crossed_threshold",
-                "volley_mode", "volley_size", "missiles_intercepted", "missiles_remaining", "TimeLimit.truncated"):
+                "volley_mode", "volley_size", "missiles_intercepted", "missiles_remaining", "missile_min_distances",
+                "TimeLimit.truncated"):
         assert key in info, key
     assert info["interceptor_pos"].shape == (3,) and info["missile_pos"].shape == (3,) and info["steps"] == 1
+    assert info["missile_min_distances"] == [info["distance"]]           # environment.py:848 outside volley mode
     st = env.get_state()
     assert np.allclose(info["interceptor_pos"], list(st[3].int_pos)) and np.allclose(info["missile_pos"], list(st[3].mis_pos))
     assert abs(float(np.linalg.norm(info["missile_pos"] - info["interceptor_pos"])) - info["distance"]) < 1e-2
