@@ -157,6 +157,14 @@ def load(build_if_missing: bool = True):
                 time.sleep(0.5)
     if not os.path.exists(path):
         raise RuntimeError(f"HIP library not found at {path}: build it with `python -m hlynr_intercept_amd.build`")
+    # One HIP runtime per process.  PyTorch-ROCm wheels carry their own libamdhip64 / libhsa-runtime64; libhlx.so names the
+    # same SONAMEs, and whichever copy is mapped first serves every later user.  If libhlx.so came first (the system ROCm's
+    # copy) and torch afterwards, torch would run half on its own libraries and half on the system's and report "no
+    # ROCm-capable device".  So torch, when it is installed, is always mapped first; without torch the system copy is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover - plain C-ABI use
+        pass
     try:
         lib = C.CDLL(path)
     except OSError as exc:

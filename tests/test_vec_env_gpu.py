@@ -118,6 +118,21 @@ def test_radar_debug_key_and_episode_files(tmp_path):
     env.close()
 
 
+def test_library_loaded_before_torch_still_finds_the_gpu():
+    """`__graft_entry__.build()` loads libhlx.so before anything imported torch; `smoke()` may follow in the same process.
+    PyTorch-ROCm ships its own HIP runtime: the loader must make sure only one copy serves the process (_lib.load)."""
+    import os
+    import subprocess
+    import sys
+
+    code = ("from hlynr_intercept_amd import _lib; lib = _lib.load(); import numpy as np; "
+            "from hlynr_intercept_amd.vec_env import HlynrVecEnv; e = HlynrVecEnv(num_envs=8); e.reset(); "
+            "o, r, d, i = e.step(np.zeros((8, 6), np.float32)); assert o.shape == (8, 26); e.close(); print('ok')")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
 def test_closed_environment_fails_loudly():
     """A destroyed handle must not be dereferenced: calls after close() raise instead of reading freed memory."""
     env = _env(8)
