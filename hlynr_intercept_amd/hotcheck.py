@@ -9,9 +9,10 @@ instantiation of the generic variant, at 256 VGPRs with 440 B of scratch, lost `
 This script disassembles the gfx950 code object inside the BUILT library (what ships) and checks, for every
 hlx_env_kernel instantiation, each VGPR that is a v_readlane source and never a v_writelane destination (those are the
 compiler's own SGPR-spill registers, which it saves in whole-wave mode): between the vector load that fills it and its
-last v_readlane it must never be the destination of a scratch_load (spill reload: FAIL).  Other writes in that window
-(v_mov save/restore pairs of a live-range split around a region that borrows the register) are listed as information:
-they execute under the same EXEC mask on both sides and leave the lanes that did not take part untouched.
+last v_readlane it must not be written by ANYTHING (scratch reload, live-range-split copy back, another value borrowing
+the register), and no v_readlane may read a register that no vector load filled (a split COPY of a hot word, made under
+whatever EXEC mask was current).  The shipped kernels satisfy this with room to spare: the only v_readlane sources are
+the two load-filled hot words and the compiler's SGPR-spill registers.
 Usage: python -m hlynr_intercept_amd.hotcheck [libhlx.so | listing.s]; exit code 1 on a spill reload.
 hlynr_intercept_amd/build.py runs the same check after every build (`verify`)."""
 import collections
@@ -51,7 +52,7 @@ def regs(operand):
 
 
 def check(text):
-    """-> (kernels seen, [(kernel, reg, {opcode: count})] spill reloads, same for other in-window writes)."""
+    """-> (kernels seen, [(kernel, reg, {opcode: count})] violations, [] (kept for the old three-value signature))."""
     lines = [l.split("//")[0].rstrip() for l in text.split("\n")]
     label = re.compile(r"^(?:[0-9a-f]+ <)?(_ZN\S*hlx_env_kernel[^>:\s]*)>?:")
     any_label = re.compile(r"^(?:[0-9a-f]+ <\S+>:|\S+:\s*(;.*)?$)")
@@ -85,14 +86,13 @@ def check(text):
         for r in sorted(readlane_src - writelane_dst):
             loads = [pos for pos, op in writes[r] if is_load(op) and pos < first_read[r]]
             if not loads:
-                continue        # not a hot word: a value made uniform some other way (done-list compaction)
-            window = [op for pos, op in writes[r] if max(loads) < pos < last_read[r] and not is_load(op)]
-            reloads = collections.Counter(op for op in window if op.startswith("scratch_load"))
-            other = collections.Counter(op for op in window if not op.startswith("scratch_load"))
-            if reloads:
-                fail.append((name, f"v{r}", dict(reloads)))
-            if other:
-                info.append((name, f"v{r}", dict(other)))
+                # a v_readlane of a register no load filled: a COPY of a hot word (live-range split) or a computed value.
+                # A copy made under a partial EXEC mask holds only the active lanes -- same hazard as a spill reload.
+                fail.append((name, f"v{r}", {"v_readlane of a register that no vector load wrote": 1}))
+                continue
+            window = collections.Counter(op for pos, op in writes[r] if max(loads) < pos < last_read[r] and not is_load(op))
+            if window:   # scratch reload, or the register lent to other values while the hot word lives in a copy
+                fail.append((name, f"v{r}", dict(window)))
     return len(starts), fail, info
 
 
@@ -102,15 +102,14 @@ def verify(path=None):
     if n == 0:
         raise RuntimeError("hotcheck: no hlx_env_kernel instantiation found in the code object")
     if fail:
-        raise RuntimeError("hotcheck: the register allocator spilled a hot-constant register (v_readlane would read "
-                           "stale lanes): " + "; ".join(f"{k[:60]}... {r} {ops}" for k, r, ops in fail))
+        raise RuntimeError("hotcheck: the register allocator spilled, split or re-used a hot-constant register "
+                           "(v_readlane would read stale lanes): " + "; ".join(f"{k[:60]}... {r} {ops}" for k, r, ops in fail))
     return n
 
 
 if __name__ == "__main__":
     n, fail, info = check(listing(sys.argv[1] if len(sys.argv) > 1 else None))
-    print(f"{n} hlx_env_kernel instantiations checked: {len(fail)} hot-word spill reloads, {len(info)} split copies")
-    for tag, rows in (("SPILL RELOAD", fail), ("split copy", info)):
-        for name, r, ops in rows:
-            print(f"  {tag}: {name[:72]}... {r} written by {ops}")
+    print(f"{n} hlx_env_kernel instantiations checked: {len(fail)} hot-word violations")
+    for name, r, ops in fail:
+        print(f"  VIOLATION: {name[:72]}... {r}: {ops}")
     sys.exit(1 if fail or n == 0 else 0)
