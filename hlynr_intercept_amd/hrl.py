@@ -56,6 +56,9 @@ class HRLController:
         self.option = torch.zeros(n, dtype=torch.uint8, device=dev)
         self.info = torch.zeros(n, dtype=torch.uint8, device=dev)
         self._closed = False
+        # recurrent specialists (select_actions_recurrent): one live LSTM state per environment, resident on the device
+        self._fresh = torch.ones(n, dtype=torch.bool, device=dev)    # controller (re)started: the next predict begins an episode
+        self.lstm_state = None                                       # tuple of [layers, N, hidden] tensors, made on first use
 
     def _stream(self):
         return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
@@ -80,6 +83,10 @@ class HRLController:
             mask = mask.to(device=self.device, dtype=self._torch.uint8).contiguous()
             m = mask.data_ptr()
         _lib.check(self._lib.hlx_hrl_reset(self._h, m, self._stream()))
+        if mask is None:
+            self._fresh.fill_(True)
+        else:
+            self._fresh |= mask.bool()
 
     def abstract_observation(self, obs):
         """[N, 26k] observation tensor -> [N, 7] abstract state (no controller state is touched)."""
@@ -121,6 +128,40 @@ class HRLController:
             idx = t.nonzero(option == int(k)).squeeze(1)
             if idx.numel():
                 actions.index_copy_(0, idx, fn(obs.index_select(0, idx)).to(t.float32))
+        return actions, option, info
+
+    def select_actions_recurrent(self, obs, specialists: Dict[int, Callable], terminated=None, truncated=None,
+                                 action_dim: int = 6):
+        """`select_actions` for recurrent specialists (RecurrentPPO, hrl/specialist_policies.py:95-183).
+
+        `specialists[k](obs_rows, state_rows, episode_start_rows) -> (action_rows, new_state_rows)` with `state_rows` a
+        tuple of [layers, rows, hidden] tensors -- the batched form of `model.predict(obs, state=..., episode_start=...)`.
+
+        The reference keeps an LSTM state per specialist and environment, but resets a specialist's state whenever its
+        option is switched away from (manager.py:210-215) and all of them when the episode restarts (manager.py:104-107),
+        so at any time an environment has exactly ONE live state: that of its active specialist, begun afresh
+        (`episode_start=True`, i.e. zeros) on the step an option is entered or the controller restarted.  That state lives
+        here, on the device, as `self.lstm_state`; per step each specialist sees the rows of its own environments only."""
+        t = self._torch
+        option, abstract, info = self.step(obs, terminated, truncated)
+        starts = (info & 1).bool() | self._fresh
+        for flag in (terminated, truncated):            # controllers restarted by hlx_hrl_step before deciding
+            if flag is not None:
+                starts |= flag.to(self.device).bool()
+        self._fresh.zero_()
+        actions = t.zeros((self.num_envs, action_dim), dtype=t.float32, device=self.device)
+        for k, fn in specialists.items():
+            idx = t.nonzero(option == int(k)).squeeze(1)
+            if not idx.numel():
+                continue
+            rows = None if self.lstm_state is None else tuple(x.index_select(1, idx) for x in self.lstm_state)
+            act, new = fn(obs.index_select(0, idx), rows, starts.index_select(0, idx))
+            actions.index_copy_(0, idx, act.to(t.float32))
+            if self.lstm_state is None:                 # shapes come from the first specialist that answers
+                self.lstm_state = tuple(t.zeros((x.shape[0], self.num_envs, x.shape[2]), dtype=x.dtype, device=self.device)
+                                        for x in new)
+            for bank, x in zip(self.lstm_state, new):
+                bank.index_copy_(1, idx, x)
         return actions, option, info
 
     @staticmethod

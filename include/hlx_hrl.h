@@ -14,7 +14,8 @@
  * What stays outside (the policies themselves): the selector network ("model" mode) and the three specialists'
  * RecurrentPPO networks are the caller's; the controller tells it, per environment, which option is active and
  * whether the selector is due, and takes the selector's choices back.  hlynr_intercept_amd/hrl.py groups the
- * specialists' forward passes by active option.
+ * specialists' forward passes by active option and keeps recurrent specialists' LSTM states in a device-resident
+ * bank (one live state per environment: manager.py:104-107, 210-215).
  *
  * All array arguments are DEVICE pointers; nothing synchronises; every function returns an hlx_status (hlx.h).
  */

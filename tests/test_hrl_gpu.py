@@ -127,3 +127,66 @@ def test_select_actions_groups_specialists_by_option():
     d = HRLController.decode_info(int(info[0]))
     assert set(d) == {"hrl/option_switched", "hrl/switch_reason", "hrl/forced_transition", "hrl/selector_due", "hrl/selector_choice"}
     env.close(); ctl.close()
+
+
+def test_recurrent_specialists_keep_one_live_lstm_state_per_environment():
+    """manager.py:104-107 (reset: every specialist's LSTM state dropped) and :210-215 (switch: the old option's state
+    dropped) leave each environment with exactly one live state, started afresh when an option is entered.  Emulated here
+    per environment in Python (options from the pinned oracle controller), against the batched on-device state bank."""
+    import torch
+    from hlynr_intercept_amd.hrl import HRLController
+    from oracle.hrl_controller import Controller
+    n, T, H = 777, 300, 5
+    rng = np.random.default_rng(11)
+    kw = dict(decision_interval=9)
+    g = HRLController(n, obs_dim=26, **kw)
+    o = Controller(n, selector="rules", **kw)
+    gains = {0: 0.25, 1: 0.5, 2: 0.75}          # three different "networks": h' = gain * h + mean(obs); c' = c + 1
+
+    def make(k):
+        def f(rows, state, starts):
+            L = 2
+            if state is None:
+                state = (torch.zeros((L, rows.shape[0], H), device=rows.device), torch.zeros((L, rows.shape[0], H), device=rows.device))
+            h, c = state
+            keep = (~starts).to(h.dtype)[None, :, None]                      # episode_start -> zeros (RecurrentPPO semantics)
+            h2 = gains[k] * h * keep + rows.mean(1)[None, :, None]
+            c2 = c * keep + 1.0
+            act = torch.zeros((rows.shape[0], 6), device=rows.device)
+            act[:, 0] = h2[1, :, 0]; act[:, 1] = c2[0, :, 0]; act[:, 2] = float(k)
+            return act, (h2, c2)
+        return f
+
+    spec = {k: make(k) for k in gains}
+    h_ref = np.zeros(n, np.float64); c_ref = np.zeros(n, np.float64)
+    live = np.zeros(n, bool)                                                    # a state exists (not None)
+    lock = rng.random(n).astype(np.float32); dist = rng.uniform(50, 600, n).astype(np.float32)
+    done = np.zeros(n, bool)
+    for t in range(T):
+        lock = np.clip(lock + rng.normal(0, 0.08, n), 0, 1).astype(np.float32)
+        dist = np.clip(dist + rng.normal(-1, 15, n), 1, 900).astype(np.float32)
+        obs = rng.uniform(-1, 1, (n, 26)).astype(np.float32)
+        d = rng.standard_normal((n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        obs[:, 0:3] = (d * dist[:, None]).astype(np.float32); obs[:, 12] = 0.8; obs[:, 14] = lock
+        r = o.step(obs, done, None)
+        # reference semantics, one environment at a time
+        live[done] = False                                                      # manager.reset(): all states None
+        live[r["switched"]] = False                                             # the specialist entered has no state yet
+        gain = np.array([gains[int(k)] for k in r["option"]])
+        m = obs.astype(np.float32).mean(1, dtype=np.float32).astype(np.float64)
+        h_ref = np.where(live, gain * h_ref, 0.0) + m
+        c_ref = np.where(live, c_ref, 0.0) + 1.0
+        live[:] = True
+        acts, opt, info = g.select_actions_recurrent(torch.tensor(obs, device=g.device), spec,
+                                                     torch.tensor(done.astype(np.uint8), device=g.device), None)
+        a = acts.cpu().numpy()
+        assert np.array_equal(opt.cpu().numpy(), r["option"].astype(np.uint8)), t
+        assert np.array_equal(a[:, 2], r["option"].astype(np.float32)), t
+        assert np.allclose(a[:, 0], h_ref, rtol=1e-5, atol=1e-5), (t, np.abs(a[:, 0] - h_ref).max())
+        assert np.array_equal(a[:, 1], c_ref.astype(np.float32)), t              # exact: counts steps since the state began
+        done = rng.random(n) < 0.02
+    assert g.lstm_state[0].shape == (2, n, H) and c_ref.max() > 20 and (c_ref == 1).any()
+    g.reset()                                                                    # HierarchicalManager.reset(): everything starts afresh
+    acts, _, _ = g.select_actions_recurrent(torch.tensor(obs, device=g.device), spec, None, None)
+    assert torch.all(acts[:, 1] == 1.0)
+    g.close()
