@@ -56,8 +56,6 @@ namespace {
 #define STAMP2(k) do { } while (0)
 #endif
 
-DEV double rr(double x, bool is64) { return is64 ? x : (double)(float)x; }
-
 // State / ring / observation stores are WRITE-THROUGH (`sc1`) buffer stores: nothing this launch stores is read
 // again before the next launch (whose acquire drops the L2 anyway), and with plain stores the ~21 MB a launch
 // writes would sit dirty in the XCD L2s until the end-of-kernel release writes it all back at once, after the
@@ -951,20 +949,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                         }
                     } else if (d_on_det) { m64 = false; z = to_d3(d_on); }
                     else { m64 = d_g64; z = d_gp64; }
-                    z = d3(rr((double)ipos.x + z.x, m64), rr((double)ipos.y + z.y, m64), rr((double)ipos.z + z.z, m64)); // :749
+                    // The filter runs in the dtype numpy's promotion gives it: float32 while state and measurement are
+                    // float32, float64 from the first float64 (ground) measurement on.  Two code paths instead of
+                    // rounding every float64 result back to float32 under a per-lane flag: a float32 operation IS the
+                    // float64 operation rounded once more (53 >= 2*24 + 2 bits: double rounding is innocuous for
+                    // + - * / sqrt), so the float32 path below is bit-identical to that emulation, and a wave whose
+                    // lanes agree on the dtype -- the usual case -- executes one path of plain arithmetic.
+                    const D3 zw = d3((double)ipos.x + z.x, (double)ipos.y + z.y, (double)ipos.z + z.z);            // :749
+                    const V3 zf = to_v3(zw);                                        // the float32 measurement (when !m64)
                     if (!kf_init) {                                                 // core.py:93-96
-                        kxp = d3((double)(float)z.x, (double)(float)z.y, (double)(float)z.z);
+                        kxp = to_d3(zf);
                         kxv = d3(0., 0., 0.);
                         kf_init = true;
                     } else {                                                        // core.py:98-116 on the 2x2 blocks
                         const bool y64 = m64 || kf_x64;
                         const float sinv = HLX_DIVF(1.0f, p_pp + 400.f);
                         const float kp = p_pp * sinv, kv = p_vp * sinv;
-                        D3 y = d3(rr(z.x - kxp.x, y64), rr(z.y - kxp.y, y64), rr(z.z - kxp.z, y64));
-                        kxp = d3(rr(kxp.x + rr((double)kp * y.x, y64), y64), rr(kxp.y + rr((double)kp * y.y, y64), y64),
-                                 rr(kxp.z + rr((double)kp * y.z, y64), y64));
-                        kxv = d3(rr(kxv.x + rr((double)kv * y.x, y64), y64), rr(kxv.y + rr((double)kv * y.y, y64), y64),
-                                 rr(kxv.z + rr((double)kv * y.z, y64), y64));
+                        if (y64) {
+                            const D3 zz = m64 ? zw : to_d3(zf);
+                            const D3 y = zz - kxp;
+                            kxp = d3(kxp.x + (double)kp * y.x, kxp.y + (double)kp * y.y, kxp.z + (double)kp * y.z);
+                            kxv = d3(kxv.x + (double)kv * y.x, kxv.y + (double)kv * y.y, kxv.z + (double)kv * y.z);
+                        } else {
+                            const V3 xp = to_v3(kxp), xv = to_v3(kxv);             // exact: the state is float32-valued
+                            const V3 y = zf - xp;
+                            kxp = to_d3(v3(xp.x + kp * y.x, xp.y + kp * y.y, xp.z + kp * y.z));
+                            kxv = to_d3(v3(xv.x + kv * y.x, xv.y + kv * y.y, xv.z + kv * y.z));
+                        }
                         kf_x64 = y64;
                         const float omk = 1.0f - kp, nkv = 0.f - kv;
                         const float npp = omk * p_pp, npv = omk * p_pv;
@@ -974,9 +985,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     have_track = true;
                 } else {                                                            // :760-774
                     if (kf_init) {                                                  // core.py:80-89 predict
-                        const double dtf = (double)HOT(c.dt);
-                        kxp = d3(rr(kxp.x + rr(dtf * kxv.x, kf_x64), kf_x64), rr(kxp.y + rr(dtf * kxv.y, kf_x64), kf_x64),
-                                 rr(kxp.z + rr(dtf * kxv.z, kf_x64), kf_x64));
+                        if (kf_x64) {
+                            const double dtf = (double)HOT(c.dt);
+                            kxp = d3(kxp.x + dtf * kxv.x, kxp.y + dtf * kxv.y, kxp.z + dtf * kxv.z);
+                        } else {
+                            const V3 xp = to_v3(kxp), xv = to_v3(kxv);
+                            kxp = to_d3(v3(xp.x + HOT(c.dt) * xv.x, xp.y + HOT(c.dt) * xv.y, xp.z + HOT(c.dt) * xv.z));
+                        }
                         const float a_pp = p_pp + HOT(c.dt) * p_vp, a_pv = p_pv + HOT(c.dt) * p_vv;
                         const float n_pp = a_pp + a_pv * HOT(c.dt), n_vp = p_vp + p_vv * HOT(c.dt);
                         p_pp = n_pp + HOT(c.q11); p_pv = a_pv + HOT(c.q12); p_vp = n_vp + HOT(c.q12); p_vv = p_vv + HOT(c.q22);
@@ -990,9 +1005,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     // filtered relative position / velocity in the Kalman state's dtype (:758-759,:767-768); the
                     // target-velocity estimate frv + ivel (:861) cancels back to the (small) Kalman velocity, so it
                     // is formed before anything is narrowed to float32
-                    const D3 frp64 = d3(rr(kxp.x - (double)ipos.x, kf_x64), rr(kxp.y - (double)ipos.y, kf_x64), rr(kxp.z - (double)ipos.z, kf_x64));
-                    const D3 frv64 = d3(rr(kxv.x - (double)ivel.x, kf_x64), rr(kxv.y - (double)ivel.y, kf_x64), rr(kxv.z - (double)ivel.z, kf_x64));
-                    const V3 frp = to_v3(frp64), frv = to_v3(frv64);
+                    // (narrowing the float64 difference once gives the float32 difference too: innocuous double rounding)
+                    const D3 frv64 = d3(kxv.x - (double)ivel.x, kxv.y - (double)ivel.y, kxv.z - (double)ivel.z);
+                    const V3 frp = v3((float)(kxp.x - (double)ipos.x), (float)(kxp.y - (double)ipos.y), (float)(kxp.z - (double)ipos.z));
+                    const V3 frv = to_v3(frv64);
                     const float rrange = fnorm_out(frp);
                     const float closing = -fdiv(fdot(frp, frv), rrange + 1e-6f);    // :786
                     if (HAS(HLX_F_OBS_LOS)) {                                       // :791-868
@@ -1006,8 +1022,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                         row[3] = clampf(fdot(rate, v) * 2.0f, -1.f, 1.f);
                         float ivm = fnorm_out(ivel);
                         row[4] = (ivm > 1e-6f) ? fdiv(fdot(ivel, lu), ivm) : 0.f;    // :852-858
-                        V3 tv = to_v3(d3(rr(frv64.x + (double)ivel.x, kf_x64), rr(frv64.y + (double)ivel.y, kf_x64),
-                                         rr(frv64.z + (double)ivel.z, kf_x64)));                // :861
+                        V3 tv = kf_x64 ? v3((float)(frv64.x + (double)ivel.x), (float)(frv64.y + (double)ivel.y), (float)(frv64.z + (double)ivel.z))
+                                       : v3(frv.x + ivel.x, frv.y + ivel.y, frv.z + ivel.z);   // :861
                         float tvm = fnorm_out(tv);
                         row[5] = (tvm > 1e-6f) ? -fdiv(fdot(tv, lu), tvm) : 0.f;
                         row[6] = clampf(ivm * inv_mv, 0.f, 1.f);                    // :924-925
