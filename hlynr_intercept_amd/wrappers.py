@@ -18,12 +18,89 @@ from __future__ import annotations
 
 import ctypes as C
 import pickle
-from typing import Any, Optional
+from typing import Any, Dict, Optional
 
 import numpy as np
 
 from . import _lib
 from .vec_env import HlynrVecEnv, _SB3VecEnv, _box
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# vec_normalize.pkl compatibility (no GPU needed for any of this)
+class _Opaque:
+    """Stand-in for a class a pickle names but this interpreter cannot import (stable_baselines3 / gymnasium objects
+    inside an SB3 VecNormalize pickle): keeps the attributes, nothing else."""
+
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def __setstate__(self, state):
+        if isinstance(state, tuple) and len(state) == 2:      # (dict, slots-dict) form
+            for part in state:
+                if isinstance(part, dict):
+                    self.__dict__.update(part)
+        elif isinstance(state, dict):
+            self.__dict__.update(state)
+
+
+class _TolerantUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        try:
+            return super().find_class(module, name)
+        except (ImportError, AttributeError):
+            return type(name, (_Opaque,), {"__module__": module})
+
+
+def read_vecnormalize_pickle(path: str) -> Dict[str, Any]:
+    """Statistics and settings from a `vec_normalize.pkl`: this module's dict format, or an SB3 `VecNormalize` object
+    (attribute names of stable_baselines3/common/vec_env/vec_normalize.py), importable or not."""
+    with open(path, "rb") as f:
+        obj = _TolerantUnpickler(f).load()
+    if isinstance(obj, dict) and obj.get("format") == "hlynr-vecnormalize-v1":
+        return obj
+    try:
+        return {"obs_mean": np.asarray(obj.obs_rms.mean, np.float64), "obs_var": np.asarray(obj.obs_rms.var, np.float64),
+                "obs_count": float(obj.obs_rms.count), "ret_mean": float(np.asarray(obj.ret_rms.mean)),
+                "ret_var": float(np.asarray(obj.ret_rms.var)), "ret_count": float(obj.ret_rms.count),
+                "clip_obs": float(obj.clip_obs), "clip_reward": float(obj.clip_reward), "gamma": float(obj.gamma),
+                "epsilon": float(obj.epsilon), "norm_obs": bool(obj.norm_obs), "norm_reward": bool(obj.norm_reward),
+                "training": bool(obj.training)}
+    except AttributeError as exc:
+        raise ValueError(f"{path}: neither this module's format nor an SB3 VecNormalize pickle ({exc})") from exc
+
+
+def write_vecnormalize_pickle(path: str, state: Dict[str, Any], observation_space, action_space, num_envs: int) -> str:
+    """Writes `state` (VecNormalize.state_dict()) as an SB3 `VecNormalize` pickle when stable-baselines3 is importable
+    (returns "sb3"), else in this module's dict format (returns "dict")."""
+    try:
+        from stable_baselines3.common.running_mean_std import RunningMeanStd
+        from stable_baselines3.common.vec_env import VecNormalize as _SB3VecNormalize
+    except Exception:
+        with open(path, "wb") as f:
+            pickle.dump(state, f)
+        return "dict"
+
+    def rms(mean, var, count, shape):
+        r = RunningMeanStd(shape=shape)
+        r.mean, r.var, r.count = np.asarray(mean, np.float64).reshape(shape), np.asarray(var, np.float64).reshape(shape), float(count)
+        return r
+
+    F = int(np.asarray(state["obs_mean"]).size)
+    obj = object.__new__(_SB3VecNormalize)
+    # the attribute set of SB3 2.x's VecNormalize.__init__ (+ VecEnvWrapper / VecEnv bookkeeping); __getstate__ drops
+    # venv, class_attributes and returns, which therefore only have to exist
+    obj.__dict__.update(dict(
+        venv=None, class_attributes={}, returns=np.zeros(int(num_envs)), num_envs=int(num_envs),
+        observation_space=observation_space, action_space=action_space, render_mode=None,
+        norm_obs_keys=None, obs_rms=rms(state["obs_mean"], state["obs_var"], state["obs_count"], (F,)),
+        ret_rms=rms(state["ret_mean"], state["ret_var"], state["ret_count"], ()),
+        clip_obs=float(state["clip_obs"]), clip_reward=float(state["clip_reward"]), gamma=float(state["gamma"]),
+        epsilon=float(state["epsilon"]), training=bool(state["training"]), norm_obs=bool(state["norm_obs"]),
+        norm_reward=bool(state["norm_reward"]), old_obs=np.array([]), old_reward=np.array([])))
+    with open(path, "wb") as f:
+        pickle.dump(obj, f)
+    return "sb3"
 
 
 class _RmsView:
@@ -259,23 +336,16 @@ class VecNormalize(_DeviceObsWrapper):
                 "training": self._training, "n_stack": self.n_stack}
 
     def save(self, path: str) -> None:
-        """Pickle of the running statistics and settings (a plain dict; `load` also accepts an SB3 VecNormalize pickle)."""
-        with open(path, "wb") as f:
-            pickle.dump(self.state_dict(), f)
+        """`VecNormalize.save` (train_flat_ppo.py:528-531).  Where stable-baselines3 is importable the file is a genuine
+        SB3 `VecNormalize` pickle (the reference's `inference.py:450-477` loads it with SB3's own `VecNormalize.load`);
+        elsewhere a plain dict with the same numbers.  `load` reads both, with or without SB3 installed."""
+        write_vecnormalize_pickle(path, self.state_dict(), self.observation_space, self.action_space, self.num_envs)
 
     @staticmethod
     def load(path: str, venv) -> "VecNormalize":
-        """Counterpart of SB3's `VecNormalize.load(load_path, venv)`.  Reads this module's own format, or -- where
-        stable-baselines3 is importable -- a `vec_normalize.pkl` written by the reference's trainers."""
-        with open(path, "rb") as f:
-            obj = pickle.load(f)
-        if isinstance(obj, dict) and obj.get("format") == "hlynr-vecnormalize-v1":
-            d = obj
-        else:   # an SB3 VecNormalize instance: same attribute names
-            d = {"obs_mean": obj.obs_rms.mean, "obs_var": obj.obs_rms.var, "obs_count": obj.obs_rms.count,
-                 "ret_mean": obj.ret_rms.mean, "ret_var": obj.ret_rms.var, "ret_count": obj.ret_rms.count,
-                 "clip_obs": obj.clip_obs, "clip_reward": obj.clip_reward, "gamma": obj.gamma, "epsilon": obj.epsilon,
-                 "norm_obs": obj.norm_obs, "norm_reward": obj.norm_reward, "training": obj.training}
+        """Counterpart of SB3's `VecNormalize.load(load_path, venv)`: this module's own format or a `vec_normalize.pkl`
+        written by SB3 (the reference's trainers) -- the latter also where SB3 itself is not installed."""
+        d = read_vecnormalize_pickle(path)
         out = VecNormalize(venv, training=d["training"], norm_obs=d["norm_obs"], norm_reward=d["norm_reward"],
                            clip_obs=d["clip_obs"], clip_reward=d["clip_reward"], gamma=d["gamma"], epsilon=d["epsilon"])
         out._set_stats(np.asarray(d["obs_mean"], np.float64).reshape(-1), np.asarray(d["obs_var"], np.float64).reshape(-1),
