@@ -145,3 +145,40 @@ def test_sb3_numpy_contract_of_the_wrapped_env():
     env.env_method("set_training_step_count", 1234)                                 # passes through to the base env
     assert env.get_attr("observation_generator")[0].radar_beam_width > 0
     env.close()
+
+
+@pytest.mark.parametrize("n,n_stack", [(4099, 4), (300, 2), (70, 8)])
+def test_incremental_moments_equal_the_full_reduction(n, n_stack):
+    """Step pushes that follow a training push reduce only the newest frame and subtract the frames of the environments
+    that were reset (hlx_obs_moments_inc_kernel); HLX_OBS_FULL_MOMENTS=1 forces the full reduction over all n_stack frames.
+    Same batches, both ways: the running statistics agree to float64 rounding, including across eval-mode gaps."""
+    import torch
+    from hlynr_intercept_amd.wrappers import VecFrameStack, VecNormalize
+    T = 90
+    stats = {}
+    for full in (False, True):
+        if full:
+            os.environ["HLX_OBS_FULL_MOMENTS"] = "1"
+        try:
+            w = VecNormalize(VecFrameStack(_make(n, seed=21, max_steps=17), n_stack), norm_reward=True)
+            g = torch.Generator(device=w.device).manual_seed(8)
+            acts = torch.rand((T, n, 6), generator=g, device=w.device) * 2 - 1
+            w.reset_torch()
+            snaps = []
+            for t in range(T):
+                if t == 40:
+                    w.training = False          # statistics frozen: the next training push must fall back to the full form
+                if t == 47:
+                    w.training = True
+                w.step_torch(acts[t])
+                if t % 10 == 9:
+                    snaps.append((w.obs_rms.mean.copy(), w.obs_rms.var.copy(), w.obs_rms.count, w.ret_rms.var))
+            stats[full] = snaps
+            w.close()
+        finally:
+            os.environ.pop("HLX_OBS_FULL_MOMENTS", None)
+    for (m0, v0, c0, r0), (m1, v1, c1, r1) in zip(stats[False], stats[True]):
+        assert c0 == c1 and r0 == r1
+        assert np.max(np.abs(m0 - m1)) <= 1e-12 * max(1.0, np.max(np.abs(m1)))
+        assert np.max(np.abs(v0 - v1)) <= 1e-11 * max(1.0, np.max(np.abs(v1)))
+    assert stats[False][-1][2] > n * 70      # the statistics did advance
