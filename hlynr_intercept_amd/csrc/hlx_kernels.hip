@@ -125,7 +125,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
     //      rollout writes slot k mod out_slots of the [out_slots][N][...] output arrays)
     const int T, const int out_slot0, const int out_slots) {
     __shared__ __attribute__((aligned(16))) float tile[64 * HLX_OBS_DIM];
-    const uint32_t FL = (SPEC & KF_DYNAMIC) ? P->hot.c.flags : SPEC;   // generic variant only: one scalar load
+    // generic variants read the feature flags at run time (one scalar load) -- except volley mode, whose K-missile loops
+    // are compiled in or out: the generic variant comes with and without them (KF_DYNAMIC [| HLX_F_VOLLEY])
+    const uint32_t FL = (SPEC & KF_DYNAMIC) ? ((P->hot.c.flags & ~(uint32_t)HLX_F_VOLLEY) | (SPEC & (uint32_t)HLX_F_VOLLEY)) : SPEC;
     const int lane = threadIdx.x;
     const int i = blockIdx.x * 64 + lane;
     const bool live = i < n;
