@@ -124,11 +124,22 @@ class HRLController:
         t = self._torch
         option, abstract, info = self.step(obs, terminated, truncated)
         actions = t.zeros((self.num_envs, action_dim), dtype=t.float32, device=self.device)
-        for k, fn in specialists.items():
-            idx = t.nonzero(option == int(k)).squeeze(1)
-            if idx.numel():
-                actions.index_copy_(0, idx, fn(obs.index_select(0, idx)).to(t.float32))
+        for k, idx in self._rows_by_option(option, specialists):
+            actions.index_copy_(0, idx, specialists[k](obs.index_select(0, idx)).to(t.float32))
         return actions, option, info
+
+    def _rows_by_option(self, option, specialists):
+        """(option, row indices ascending) for every option that has a specialist and at least one environment: one stable
+        sort and ONE host synchronisation (the three group sizes) instead of a `nonzero` -- and a sync -- per option."""
+        t = self._torch
+        perm = t.argsort(option, stable=True)
+        counts = t.bincount(option.to(t.int64), minlength=3).tolist()
+        out, start = [], 0
+        for k in range(len(counts)):
+            if counts[k] and k in specialists:
+                out.append((k, perm[start:start + counts[k]]))
+            start += counts[k]
+        return out
 
     def select_actions_recurrent(self, obs, specialists: Dict[int, Callable], terminated=None, truncated=None,
                                  action_dim: int = 6):
@@ -150,10 +161,8 @@ class HRLController:
                 starts |= flag.to(self.device).bool()
         self._fresh.zero_()
         actions = t.zeros((self.num_envs, action_dim), dtype=t.float32, device=self.device)
-        for k, fn in specialists.items():
-            idx = t.nonzero(option == int(k)).squeeze(1)
-            if not idx.numel():
-                continue
+        for k, idx in self._rows_by_option(option, specialists):
+            fn = specialists[k]
             rows = None if self.lstm_state is None else tuple(x.index_select(1, idx) for x in self.lstm_state)
             act, new = fn(obs.index_select(0, idx), rows, starts.index_select(0, idx))
             actions.index_copy_(0, idx, act.to(t.float32))
