@@ -97,6 +97,9 @@ SYMBOLS = {
     "hlx_get_state": (C.c_int, [_P, _P]),
     "hlx_set_state": (C.c_int, [_P, _P]),
     "hlx_set_rollout_fused": (C.c_int, [_P, i32]),
+    "hlx_set_seed": (C.c_int, [_P, u64]),
+    "hlx_set_load_schedule": (C.c_int, [_P, i32]),
+    "hlx_get_load_schedule": (i32, [_P]),
     "hlx_profile": (C.c_int, [_P, i32]),
     "hlx_profile_read": (C.c_int, [_P, C.POINTER(f64), C.POINTER(i64)]),
     "hlx_num_envs": (i32, [_P]),

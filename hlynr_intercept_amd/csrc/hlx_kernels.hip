@@ -1170,8 +1170,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             base = __shfl(base, 0);
             if (live && done) done_idx_out[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
         }
-        if (blockIdx.x == 0 && lane == 0) P->done_cnt[(int)((t + 1ull) & 1ull)] = 0;   // arm the other counter
     }
+    // Every step launch arms the counter of the NEXT vec step, whether or not this one compacts: listed and unlisted
+    // steps (hlx_step without done_idx, hlx_rollout, the fused rollout) may interleave freely.
+    if (MODE == 0 && !PERSIST && blockIdx.x == 0 && lane == 0) P->done_cnt[(int)((t + 1ull) & 1ull)] = 0;
 
     // -------------------------------------------------------------------------- observation tile -> [N][26]
     if (obs_out) {
@@ -1210,6 +1212,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         __syncthreads();   // the tile is rewritten by the next step
     }
     }   // step loop
+    if (PERSIST && blockIdx.x == 0 && lane == 0) { P->done_cnt[0] = 0; P->done_cnt[1] = 0; }   // nothing was listed in this launch
     if (PERSIST && live) {   // state back to the arena, once
         STG(G_IPOS, g_ipos); STG(G_IVEL, g_ivel); STG(G_QUAT, g_quat); STG(G_MPOS, g_mpos); STG(G_MVEL, g_mvel);
         STG(G_W0, g_w0); STG(G_W1, g_w1);

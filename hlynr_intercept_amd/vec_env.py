@@ -398,8 +398,20 @@ class HlynrVecEnv(_SB3VecEnv):
         return self.step_wait()
 
     def seed(self, seed: Optional[int] = None):
-        """SB3 `VecEnv.seed`: the RNG is counter-based and keyed at construction; re-keying = new env set."""
+        """SB3 `VecEnv.seed` (`set_random_seed`, scripts/compare_policies.py:150): re-keys the counter-based RNG -- env i
+        draws from Philox(seed, env_id_offset + i, vec-step clock) from the next launch on; SB3 callers follow with
+        `reset()`.  `None` keeps the current key, as `gym.Env.reset(seed=None)` keeps its generator."""
+        if seed is not None:
+            _lib.check(self._lib.hlx_set_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF))
         return [seed] * self.num_envs
+
+    def set_load_schedule(self, mode: int):
+        """-1 auto (by batch size), 0 all loads at kernel entry, 1 Kalman / ring loads behind the Philox block (hlx.h)."""
+        _lib.check(self._lib.hlx_set_load_schedule(self._h, int(mode)))
+
+    @property
+    def load_schedule(self) -> int:
+        return int(self._lib.hlx_get_load_schedule(self._h))
 
     def _indices(self, indices):
         if indices is None:

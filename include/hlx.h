@@ -185,6 +185,12 @@ int hlx_destroy(hlx_env *env);
  * obs_out: device float[N][26] (rows of envs that are not reset are left untouched), may be NULL. */
 int hlx_reset(hlx_env *env, const uint8_t *mask, float *obs_out, void *stream);
 
+/* Re-key the counter-based RNG (gym's `reset(seed=...)` / SB3's `VecEnv.seed`, scripts/compare_policies.py:150): env i
+ * draws from Philox(seed, env_id_offset + i, vec-step clock) from the next launch on.  Follow with hlx_reset to start
+ * episodes that depend on the new seed only through (seed, clock).  Successive hlx_reset calls at one clock value draw
+ * different episodes (a reset epoch is part of the counter); hlx_set_seed restarts that epoch. */
+int hlx_set_seed(hlx_env *env, uint64_t seed);
+
 /* environment.py:605 step() for all N envs, with VecEnv auto-reset: an env that terminates or
  * truncates is reset inside the same launch; `obs` then holds the first observation of the new
  * episode and `terminal_obs[i]` (if not NULL) the last one of the finished episode.
@@ -234,9 +240,16 @@ int hlx_profile(hlx_env *env, int32_t enable);
  * (synchronises, then clears) */
 int hlx_profile_read(hlx_env *env, double *total_ms, int64_t *launches);
 
+/* Load schedule of the step kernel (two instantiations of the same source, bit-identical results): 1 = the Kalman
+ * groups and the delayed ground-ring sample are loaded as a second batch behind the Philox block (best while a SIMD
+ * holds at most two waves), 0 = everything at entry (best once HBM-bound), -1 = choose from the batch size
+ * (the default at hlx_create).  hlx_get_load_schedule returns the schedule in force. */
+int hlx_set_load_schedule(hlx_env *env, int32_t mode);
+int32_t hlx_get_load_schedule(const hlx_env *env);
+
 int32_t hlx_num_envs(const hlx_env *env);
 int64_t hlx_vec_steps(const hlx_env *env);              /* launches so far (the RNG/ring clock) */
-const char *hlx_kernel_variant(const hlx_env *env);     /* "base", "v2dr" or "generic" */
+const char *hlx_kernel_variant(const hlx_env *env);     /* "base", "v2", "v2dr", "config", "config-easy", "config-volley", "generic" or "generic-volley" */
 int32_t hlx_sizeof_config(void);
 int32_t hlx_sizeof_env_state(void);
 const char *hlx_last_error(void);

@@ -389,6 +389,10 @@ def run_case(name, env_cfg, n_steps, seed, policy="random", tweak=None, global_s
     from environment import InterceptEnvironment
 
     env = InterceptEnvironment(copy.deepcopy(env_cfg))
+    if env.physics_randomizer is not None:
+        # the randomiser's generator is entropy-seeded (physics_randomizer.py:128); its own seed() hook makes the
+        # domain-randomised fixtures reproducible (`--check`)
+        env.physics_randomizer.seed(seed + 4242)
     if global_step:
         env.set_training_step_count(global_step)
     arng = _orig_default_rng(seed + 77)
@@ -643,11 +647,94 @@ def tw_blind(env):
     env._episode_min_distance = env._prev_distance
 
 
+def _sync_distances(env):
+    d = np.linalg.norm(env.missile_state["position"] - env.interceptor_state["position"])
+    env._prev_distance = np.float32(d)
+    env._last_distance = env._prev_distance
+    env._episode_min_distance = env._prev_distance
+
+
+def tw_alt_11km(env):
+    # both vehicles cross the 11 km tropopause (physics_models.py:70-74, 95-108): interceptor climbing, missile descending
+    env.interceptor_state["position"][:] = np.array([10.0, 20.0, 10985.0], np.float32)
+    env.interceptor_state["velocity"][:] = np.array([30.0, 20.0, 180.0], np.float32)
+    env.missile_state["position"][:] = np.array([1500.0, 1400.0, 11020.0], np.float32)
+    env.missile_state["velocity"][:] = np.array([-120.0, -110.0, -160.0], np.float32)
+    _sync_distances(env)
+
+
+def tw_alt_20km(env):
+    # ... and the 20 km boundary of the isothermal layer (physics_models.py:72-78, 102-113)
+    env.interceptor_state["position"][:] = np.array([10.0, 20.0, 19985.0], np.float32)
+    env.interceptor_state["velocity"][:] = np.array([30.0, 20.0, 180.0], np.float32)
+    env.missile_state["position"][:] = np.array([1500.0, 1400.0, 20025.0], np.float32)
+    env.missile_state["velocity"][:] = np.array([-120.0, -110.0, -160.0], np.float32)
+    _sync_distances(env)
+
+
+def tw_ground_out_of_range(env):
+    # missile just outside the ground radar's 20 km (core.py:396-397 'out_of_range'), closing fast: comes into range mid-case
+    env.missile_state["position"][:] = np.array([14200.0, 14100.0, 1500.0], np.float32)
+    env.missile_state["velocity"][:] = np.array([-520.0, -510.0, -20.0], np.float32)
+    _sync_distances(env)
+
+
+def tw_ground_above_coverage(env):
+    # missile almost overhead of the station at (0, 0, 100): elevation > 85 deg (core.py:405-406 'above_coverage'), drifting out
+    env.missile_state["position"][:] = np.array([90.0, 60.0, 3000.0], np.float32)
+    env.missile_state["velocity"][:] = np.array([160.0, 120.0, -40.0], np.float32)
+    _sync_distances(env)
+
+
 def spin_then_random(env, rng, t):
     a = rng.uniform(-1, 1, 6).astype(np.float32)
     if (t // 40) % 2 == 0:
         a[3:6] = np.array([1.0, -1.0, 0.7], np.float32)  # tumble: beam sweeps on/off the target
     return a
+
+
+def _npz_equal(a, b):
+    fa, fb = np.load(a, allow_pickle=False), np.load(b, allow_pickle=False)
+    if sorted(fa.files) != sorted(fb.files):
+        return "key sets differ: " + str(sorted(set(fa.files) ^ set(fb.files)))
+    for k in fa.files:
+        x, y = fa[k], fb[k]
+        if x.dtype != y.dtype or x.shape != y.shape:
+            return f"{k}: {x.dtype}{x.shape} vs {y.dtype}{y.shape}"
+        same = np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y)
+        if not same:
+            return f"{k}: values differ"
+    return None
+
+
+def check():
+    """`make_golden.py --check`: regenerate every fixture from the reference into a scratch directory and compare it,
+    array by array and bit for bit, with the committed file -- fixture drift (or a reference / numpy change) shows up as
+    a named difference instead of going unnoticed."""
+    global OUT
+    import tempfile
+    committed = OUT
+    with tempfile.TemporaryDirectory() as tmp:
+        OUT = tmp
+        generate_all()
+        radar_cases(scenario_config)
+        bad, n = [], 0
+        for sub in ("", "radar"):
+            have = sorted(f for f in os.listdir(os.path.join(committed, sub)) if f.endswith(".npz"))
+            made = sorted(f for f in os.listdir(os.path.join(tmp, sub)) if f.endswith(".npz")) if os.path.isdir(os.path.join(tmp, sub)) else []
+            for f in sorted(set(have) | set(made)):
+                n += 1
+                if f not in have or f not in made:
+                    bad.append((os.path.join(sub, f), "only " + ("committed" if f in have else "regenerated")))
+                    continue
+                why = _npz_equal(os.path.join(committed, sub, f), os.path.join(tmp, sub, f))
+                if why:
+                    bad.append((os.path.join(sub, f), why))
+        OUT = committed
+    for f, why in bad:
+        print("DIFFERS", f, why)
+    print(f"check: {n - len(bad)} of {n} fixtures regenerate bit-identically")
+    return 1 if bad else 0
 
 
 def main():
@@ -658,15 +745,44 @@ def main():
     np.random.randn = _rec_randn
     _selfcheck_wrappers()
     S = scenario_config
+    if len(sys.argv) > 1 and sys.argv[1] == "--check":
+        sys.exit(check())
     if len(sys.argv) > 1 and sys.argv[1] == "radar":
         radar_cases(S)       # adds / refreshes radar/<name>.npz for a few of the cases below
         return
     if len(sys.argv) > 1 and sys.argv[1] == "volley":
         volley_cases(S)      # adds / refreshes the volley fixtures only
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "round2":
+        round2_cases(S)      # adds / refreshes the fixtures added in round 2 only
+        return
     for f in os.listdir(OUT):
         if f.endswith(".npz"):
             os.remove(os.path.join(OUT, f))
+    generate_all()
+
+
+def round2_cases(S):
+    """Round 2: the reference's own config.yaml physics (ISA atmosphere only) on the medium / hard scenarios and in volley
+    mode -- what the `config` / `config-volley` kernel variants run --, the ISA layers above 11 km / 20 km, and the two
+    ground-radar reasons no earlier trajectory reached."""
+    V = lambda k, extra=None: dict({"volley_mode": True, "volley_size": k}, **(extra or {}))  # noqa: E731
+    run_case("medium_config_random", S("medium", "config"), 400, 1200)
+    run_case("hard_config_random", S("hard", "config"), 300, 1201)
+    run_case("medium_config_pursuit", S("medium", "config"), 2000, 1202, policy="pursuit", state_every=25)
+    run_case("medium_config_short_eps", S("medium", "config", {"max_steps": 60}), 400, 1203)
+    run_case("volley3_medium_config_pursuit", S("medium", "config", V(3)), 2500, 1204, policy="pursuit", state_every=25)
+    run_case("volley3_medium_config_short_eps", S("medium", "config", V(3, {"max_steps": 50})), 300, 1205)
+    run_case("edge_isa_11km_v2", S("medium", "v2"), 120, 1210, tweak=tw_alt_11km)
+    run_case("edge_isa_20km_v2", S("medium", "v2"), 120, 1211, tweak=tw_alt_20km)
+    run_case("edge_isa_11km_config", S("medium", "config"), 120, 1212, tweak=tw_alt_11km)
+    run_case("edge_isa_20km_config", S("medium", "config"), 120, 1213, tweak=tw_alt_20km)
+    run_case("edge_ground_out_of_range", S("medium", "base"), 60, 1214, tweak=tw_ground_out_of_range, policy="coast")
+    run_case("edge_ground_above_coverage", S("medium", "base"), 60, 1215, tweak=tw_ground_above_coverage, policy="coast")
+
+
+def generate_all():
+    S = scenario_config
 
     # --- scenario x physics, random actions -------------------------------------------
     run_case("easy_config_random", S("easy", "config"), 300, 1000)
@@ -725,6 +841,7 @@ def main():
              policy=spin_then_random)
     run_case("edge_no_ground_radar", S("medium", "base", {"ground_radar": {"enabled": False}}), 100, 1062)
     volley_cases(S)
+    round2_cases(S)
 
 
 def radar_cases(S):
@@ -744,6 +861,8 @@ def radar_cases(S):
              policy=spin_then_random)
     run_case("edge_no_ground_radar", S("medium", "base", {"ground_radar": {"enabled": False}}), 100, 1062)
     run_case("volley3_medium_base_random", S("medium", "base", V(3)), 400, 1100)
+    run_case("edge_ground_out_of_range", S("medium", "base"), 60, 1214, tweak=tw_ground_out_of_range, policy="coast")
+    run_case("edge_ground_above_coverage", S("medium", "base"), 60, 1215, tweak=tw_ground_above_coverage, policy="coast")
     RADAR_ONLY = False
 
 

@@ -111,6 +111,20 @@ def test_gpu_radar_debug_matches_reference(name):
     _replay_fixture(name, load_radar_fixture(name))
 
 
+_VARIANTS_REPLAYED = {}
+
+
+def test_every_kernel_variant_replays_a_reference_fixture():
+    """Runs after the fixture replays above: each of the eight kernel variants hlx_create can select (hlx_host.inc) must
+    have been exercised by at least one trajectory recorded from the reference."""
+    if not _VARIANTS_REPLAYED:
+        pytest.skip("fixture replays were not part of this run")
+    want = {"base", "v2", "v2dr", "config", "config-easy", "config-volley", "generic", "generic-volley"}
+    if sum(len(v) for v in _VARIANTS_REPLAYED.values()) < len(fixture_names()):
+        pytest.skip("only a subset of the fixture replays ran")
+    assert want <= set(_VARIANTS_REPLAYED), want - set(_VARIANTS_REPLAYED)
+
+
 def test_radar_planes_need_the_flag():
     from hlynr_intercept_amd import _lib as hl
     from hlynr_intercept_amd.config import resolve_config
@@ -133,6 +147,8 @@ def _replay_fixture(name, radar):
     rc = resolve_config(fx["config"])
     n = 3   # same inputs in three lanes: also checks lane independence
     env = _make_env(rc, n, fx["global_step_or_none"], radar_debug=radar is not None)
+    if radar is None:
+        _VARIANTS_REPLAYED.setdefault(env.kernel_variant, []).append(name)
     dev = env.device
     T = len(fx["action"])
     radar_bad = []
@@ -242,23 +258,32 @@ def _replay_fixture(name, radar):
 # ----------------------------------------------------------------------------------------------
 # (2) GPU vs oracle, seeded random batch, free-running, Philox draws exported to the oracle
 # ----------------------------------------------------------------------------------------------
+# (scenario, physics preset, overrides, kernel variant hlx_create must select): every shipped variant is covered, and the
+# test ids carry the variant name
 CASES = [
-    ("medium", "base", {}),
-    ("medium", "v2dr", {}),
-    ("hard", "v2", {"max_steps": 150}),
-    ("easy", "config", {"observation_mode": "body_frame", "max_steps": 120}),
+    ("medium", "base", {}, "base"),
+    ("medium", "v2dr", {}, "v2dr"),
+    ("hard", "v2", {"max_steps": 150}, "v2"),
+    ("easy", "config", {"observation_mode": "body_frame", "max_steps": 120}, "generic"),
     ("medium", "v2", {"observation_mode": "los_frame", "proximity_fuze_enabled": True, "proximity_kill_radius": 60.0,
-                      "max_steps": 200}),
-    ("medium", "base", {"curriculum.precision_mode": True, "max_steps": 100}),
+                      "max_steps": 200}, "generic"),
+    ("medium", "base", {"curriculum.precision_mode": True, "max_steps": 100}, "generic"),
     # volley mode: K missiles per episode (environment.py:236-267, 631-692, 724-748)
-    ("medium", "base", {"volley_mode": True, "volley_size": 3, "max_steps": 200}),
+    ("medium", "base", {"volley_mode": True, "volley_size": 3, "max_steps": 200}, "generic-volley"),
     ("medium", "v2dr", {"volley_mode": True, "volley_size": 4, "proximity_fuze_enabled": True, "proximity_kill_radius": 80.0,
-                        "max_steps": 150}),
+                        "max_steps": 150}, "generic-volley"),
+    # the reference's own config.yaml physics (ISA atmosphere only): what train_flat_ppo.py / inference.py run out of the box
+    ("medium", "config", {}, "config"),
+    ("hard", "config", {"max_steps": 180}, "config"),
+    ("easy", "config", {"max_steps": 150}, "config-easy"),
+    ("medium", "config", {"volley_mode": True, "volley_size": 3, "max_steps": 200}, "config-volley"),
 ]
+CASE_IDS = [f"{v}-{s}-{p}-{i}" for i, (s, p, o, v) in enumerate(CASES)]
 
 
-@pytest.mark.parametrize("scenario,physics,over", CASES)
-def test_gpu_matches_oracle_free_running(scenario, physics, over):
+@pytest.mark.parametrize("late", [1, 0], ids=["late-loads", "entry-loads"])
+@pytest.mark.parametrize("scenario,physics,over,variant", CASES, ids=CASE_IDS)
+def test_gpu_matches_oracle_free_running(scenario, physics, over, variant, late):
     torch = _torch()
     import oracle.oracle as orc
     from hlynr_intercept_amd.config import resolve_config
@@ -267,6 +292,8 @@ def test_gpu_matches_oracle_free_running(scenario, physics, over):
     rc = resolve_config(scenario_config(scenario, physics, over))
     n, T = 1024, 260
     env = _make_env(rc, n, seed=1234)
+    assert env.kernel_variant == variant, (env.kernel_variant, variant)
+    env.set_load_schedule(late)      # both load schedules of the production kernel (the large-batch one is the 4 M-env roofline point)
     ora = orc.OracleVec(rc, n)
     g = torch.Generator(device="cpu").manual_seed(7)
     sn, rn = env.fill_noise(for_reset=True)
@@ -340,8 +367,9 @@ def test_gpu_matches_oracle_free_running(scenario, physics, over):
     env.close()
 
 
-@pytest.mark.parametrize("scenario,physics,over", [c for c in CASES if c[1] != "base"][:3] + [CASES[-1]])
-def test_gpu_matches_oracle_from_identical_state(scenario, physics, over):
+_RESYNC = [1, 2, 3, 7, 8, 11]
+@pytest.mark.parametrize("scenario,physics,over,variant", [CASES[i] for i in _RESYNC], ids=[CASE_IDS[i] for i in _RESYNC])
+def test_gpu_matches_oracle_from_identical_state(scenario, physics, over, variant):
     """Single-step parity: before every step the GPU arena is overwritten with the oracle's state, so
     differences cannot accumulate.  Exercises set_state/get_state with rings and Kalman state as well."""
     torch = _torch()
@@ -352,6 +380,7 @@ def test_gpu_matches_oracle_from_identical_state(scenario, physics, over):
     rc = resolve_config(scenario_config(scenario, physics, over))
     n, T = 256, 120
     env = _make_env(rc, n, seed=77)
+    assert env.kernel_variant == variant
     ora = orc.OracleVec(rc, n)
     g = torch.Generator(device="cpu").manual_seed(5)
     sn, rn = env.fill_noise(for_reset=True)
@@ -379,6 +408,62 @@ def test_gpu_matches_oracle_from_identical_state(scenario, physics, over):
     assert flag_mismatch <= max(1, n * T // 2000), flag_mismatch
     assert worst_obs <= OBS_ATOL and worst_dist <= RTOL, (worst_obs, worst_dist)
     _check_reward_errors(np.concatenate(rew_errs), rc, (scenario, physics), resynced=True)
+    env.close()
+
+
+@pytest.mark.parametrize("physics,variant", [("base", "base"), ("v2dr", "v2dr")])
+def test_full_size_batch_matches_oracle(physics, variant):
+    """BASELINE.json configs 2 and 3 at their full size -- 65 536 environments on one GPU -- against the oracle, free-running
+    for 50 steps from the same Philox draws (max_steps 40: every environment is auto-reset inside the window), with the load
+    schedule hlx_create picks for this batch size."""
+    torch = _torch()
+    import oracle.oracle as orc
+    from hlynr_intercept_amd.config import resolve_config
+    from hlynr_intercept_amd.scenarios import scenario_config
+
+    rc = resolve_config(scenario_config("medium", physics, {"max_steps": 40}))
+    n, T = 65536, 50
+    env = _make_env(rc, n, seed=2024)
+    assert env.kernel_variant == variant
+    ora = orc.OracleVec(rc, n)
+    g = torch.Generator(device=env.device).manual_seed(17)
+    sn, rn = env.fill_noise(for_reset=True)
+    obs_g = env.reset_torch().cpu().numpy()
+    obs_o = ora.reset(rn.cpu().numpy().T.copy())
+    assert np.max(np.abs(obs_g - obs_o)) <= OBS_ATOL
+    alive = np.ones(n, bool)
+    worst = dict(obs=0.0, distance=0.0, reset_obs=0.0)
+    rew_errs, n_done = [], 0
+    for t in range(T):
+        a = torch.rand((n, 6), generator=g, device=env.device) * 2 - 1
+        sn, rn = env.fill_noise()
+        obs, rew, term, trunc, info = env.step_torch(a)
+        out = ora.step(a.cpu().numpy(), sn.cpu().numpy().T.copy(), rn.cpu().numpy().T.copy())
+        term_h, trunc_h = term.cpu().numpy(), trunc.cpu().numpy()
+        alive &= (term_h == out["terminated"]) & (trunc_h == out["truncated"]) & ((info["flags"].cpu().numpy() & 1) == out["intercepted"])
+        done = (term_h | trunc_h).astype(bool)
+        n_done += int(done.sum())
+        obs_h = obs.cpu().numpy()
+        step_obs_g = np.where(done[:, None], info["terminal_observation"].cpu().numpy(), obs_h)
+        step_obs_o = np.where(done[:, None], ora.terminal_obs, out["obs"])
+        eo = np.max(np.abs(step_obs_g - step_obs_o), axis=1)
+        alive &= eo <= 50 * OBS_ATOL             # a Bernoulli detection decided at a float32 boundary retires the env
+        worst["obs"] = max(worst["obs"], float(eo[alive].max(initial=0.0)))
+        rew_errs.append(_rel(rew.cpu().numpy(), out["reward"])[alive])
+        worst["distance"] = max(worst["distance"], float(_rel(info["distance"].cpu().numpy(), out["distance"])[alive].max(initial=0.0)))
+        sel = done & alive
+        if sel.any():
+            worst["reset_obs"] = max(worst["reset_obs"], float(np.max(np.abs(obs_h[sel] - out["obs"][sel]))))
+    assert n_done >= n, "every environment must have restarted inside the window"
+    assert alive.mean() >= 0.9995, f"{(~alive).sum()} of {n} envs diverged in their discrete history"
+    assert worst["obs"] <= (10 * OBS_ATOL if _uses_libm_pow(rc) else OBS_ATOL) and worst["reset_obs"] <= OBS_ATOL, worst
+    assert worst["distance"] <= RTOL, worst
+    _check_reward_errors(np.concatenate(rew_errs), rc, ("full size", physics))
+    st = np.frombuffer(env.get_state(), dtype=np.dtype(type(env.get_state()[0])))
+    so = np.frombuffer(ora.state, dtype=np.dtype(type(ora.state[0])))
+    for name in ("int_pos", "int_vel", "int_quat", "mis_pos", "mis_vel", "wind"):
+        assert np.max(_rel(st[name][alive], so[name][alive])) <= 2 * RTOL, name
+    assert np.array_equal(st["steps"][alive], so["steps"][alive])
     env.close()
 
 

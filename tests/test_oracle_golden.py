@@ -16,10 +16,15 @@ NAMES = fixture_names()
 
 
 def test_fixture_inventory():
-    assert len(NAMES) >= 30
+    assert len(NAMES) >= 54
     for must in ("medium_base_random", "medium_v2_random", "medium_v2dr_short_eps", "eval360_los_fuze_pursuit",
                  "medium_base_precision_pursuit", "edge_fuel_out", "edge_crash", "edge_early_termination",
-                 "edge_blind_kf_uninit", "edge_mach_sweep", "medium_v2_body_random", "medium_v2_los_random"):
+                 "edge_blind_kf_uninit", "edge_mach_sweep", "medium_v2_body_random", "medium_v2_los_random",
+                 # round 2: config.yaml physics (the `config` / `config-volley` kernel variants), ISA layers above 11 / 20 km,
+                 # the ground-radar reasons 'out_of_range' / 'above_coverage'
+                 "medium_config_random", "hard_config_random", "medium_config_pursuit", "volley3_medium_config_pursuit",
+                 "edge_isa_11km_v2", "edge_isa_20km_v2", "edge_isa_11km_config", "edge_isa_20km_config",
+                 "edge_ground_out_of_range", "edge_ground_above_coverage"):
         assert must in NAMES
 
 

@@ -276,3 +276,98 @@ def test_maximum_size_batch_steps_and_auto_resets():
         elif t == 3:
             assert n_done == 0                                             # all restarted, then stepped once
     env.close()
+
+
+@pytest.mark.parametrize("pattern", ["lu", "luu", "ulu", "fused"])
+def test_done_list_survives_interleaved_unlisted_steps(pattern):
+    """The done counter of vec step t is armed by launch t - 1 whatever that launch was: a listed step (`want_done_list`)
+    may follow any number of unlisted ones -- plain `step_torch`, `rollout_torch`, the fused rollout -- and still starts
+    its count from zero (round-1 advisor finding: only consecutive listed steps were covered)."""
+    import torch
+    n = 300
+    env = _env(n, physics="base", over={"max_steps": 7})      # every env truncates every 7th step: dense done lists
+    env.reset_torch()
+    g = torch.Generator(device=env.device).manual_seed(4)
+    tape = torch.rand((5, n, 6), generator=g, device=env.device) * 2 - 1
+
+    def listed():
+        a = torch.rand((n, 6), generator=g, device=env.device) * 2 - 1
+        obs, rew, term, trunc, info = env.step_torch(a, want_done_list=True)
+        n_done = int(info["n_done"].item())
+        expect = torch.nonzero((term | trunc) != 0).flatten().cpu().numpy()
+        assert n_done == len(expect), (n_done, len(expect))
+        assert np.array_equal(np.sort(info["done_idx"][:n_done].cpu().numpy()), expect)
+        return n_done
+
+    total = 0
+    for rep in range(30):
+        for c in pattern if pattern != "fused" else "l":
+            if c == "l":
+                total += listed()
+            else:
+                env.step_torch(torch.rand((n, 6), generator=g, device=env.device) * 2 - 1)
+        if pattern == "fused":
+            env.set_rollout_fused(1 + rep % 4)
+            env.rollout_torch(tape[: 1 + rep % 5], 2)
+    assert total > 0
+    env.close()
+
+
+def test_seed_rekeys_the_rng_and_successive_resets_differ():
+    """SB3 `VecEnv.seed` / `env_method('seed', s)` (scripts/compare_policies.py:150) re-key Philox: the same seed gives
+    the same episodes on one env object, a different seed different ones; and two `reset()`s at one clock value do not
+    replay the same spawns (the reference's global generator moves on between resets)."""
+    import torch
+    n = 128
+    env = _env(n, physics="v2dr", over={"max_steps": 30})
+    g = torch.Generator(device=env.device).manual_seed(0)
+    tape = torch.rand((40, n, 6), generator=g, device=env.device) * 2 - 1
+
+    def episode(seed):
+        env.seed(seed)
+        t0 = int(env._lib.hlx_vec_steps(env._h))
+        o0 = env.reset_torch().clone()
+        outs = [env.step_torch(tape[k])[0].clone() for k in range(3)]
+        return t0, o0, outs
+
+    _, a0, _ = episode(5)
+    o_again = env.reset_torch().clone()
+    assert not torch.equal(a0, o_again)                       # second reset at the same clock: new spawns
+    # same seed at a later clock: different draws (counter = clock); same (seed, clock) on a fresh object: identical
+    other = _env(n, physics="v2dr", over={"max_steps": 30}, seed=5)
+    b0 = other.reset_torch().clone()
+    fresh = _env(n, physics="v2dr", over={"max_steps": 30}, seed=99)
+    fresh.env_method("seed", 5)
+    c0 = fresh.reset_torch().clone()
+    assert torch.equal(b0, c0)
+    for k in range(3):
+        assert torch.equal(other.step_torch(tape[k])[0], fresh.step_torch(tape[k])[0])
+    fresh.seed(6)
+    assert not torch.equal(fresh.reset_torch(), c0)
+    env.close(); other.close(); fresh.close()
+
+
+@pytest.mark.parametrize("physics,over", [("base", {}), ("v2dr", {}), ("config", {}), ("config", {"volley_mode": True, "volley_size": 3}),
+                                          ("v2", {"observation_mode": "los_frame"})])
+def test_both_load_schedules_give_identical_bits(physics, over):
+    """`hlx_set_load_schedule`: the small-batch (LATE) and the large-batch instantiation of the step kernel are the same
+    arithmetic with the Kalman / ring loads issued at different points; outputs and the full state must agree bit for bit,
+    through auto-resets and a partial tail block."""
+    import torch
+    n, T = 777, 150
+    o = dict(over, max_steps=60)
+    a_env, b_env = _env(n, physics, o, seed=21), _env(n, physics, o, seed=21)
+    a_env.set_load_schedule(1); b_env.set_load_schedule(0)
+    assert (a_env.load_schedule, b_env.load_schedule) == (1, 0)
+    assert torch.equal(a_env.reset_torch(), b_env.reset_torch())
+    g = torch.Generator(device=a_env.device).manual_seed(2)
+    for t in range(T):
+        act = torch.rand((n, 6), generator=g, device=a_env.device) * 2 - 1
+        ra, rb = a_env.step_torch(act), b_env.step_torch(act)
+        for x, y in zip(ra[:4], rb[:4]):
+            assert torch.equal(x, y), t
+        assert torch.equal(ra[4]["terminal_observation"], rb[4]["terminal_observation"])
+    assert bytes(a_env.get_state()) == bytes(b_env.get_state())
+    a_env.set_load_schedule(-1)
+    assert a_env.load_schedule == 1                                         # 777 envs: small batch
+    a_env.close(); b_env.close()
