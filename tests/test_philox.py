@@ -33,6 +33,8 @@ def test_device_uniforms_are_philox4x32_10_words():
     for for_reset in (False, True):
         sn, rn = (x.cpu().numpy() for x in env.fill_noise(for_reset=for_reset))
         t = int(env._lib.hlx_vec_steps(env._h)) + (0 if for_reset else 1)
+        if for_reset:
+            t |= 1 << 48     # explicit resets carry the reset epoch (hlx_reset calls so far: one) in bits 48-55 of the counter word
         for i in (0, 1, 63, 64, 129):
             gid = offset + i
 
