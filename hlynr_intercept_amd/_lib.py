@@ -62,7 +62,7 @@ class HlxEnvState(C.Structure):
         ("wind", f64 * 3), ("kf_x", f64 * 6), ("kf_P", f32 * 4),
         ("on_delay", i32), ("on_len", i32), ("on_ring", (f32 * 4) * RING_CAP),
         ("g_len", i32), ("g_ring", (f64 * 8) * RING_CAP),
-        ("T0", f32), ("base_cd", f32), ("transonic_peak", f32), ("ep_return", f32),
+        ("T0", f64), ("base_cd", f32), ("transonic_peak_m1", f32), ("cd_super", f32), ("ep_return", f32),
         ("v_pos", (f32 * 3) * MAX_VOLLEY), ("v_vel", (f32 * 3) * MAX_VOLLEY), ("v_min", f32 * MAX_VOLLEY),
         ("v_active", i32 * MAX_VOLLEY), ("prio", i32), ("n_intercepted", i32),
     ]
@@ -98,6 +98,7 @@ SYMBOLS = {
     "hlx_set_state": (C.c_int, [_P, _P]),
     "hlx_set_rollout_fused": (C.c_int, [_P, i32]),
     "hlx_set_seed": (C.c_int, [_P, u64]),
+    "hlx_selftest_math": (C.c_int, [i32, _P, f32, _P, i64, _P]),
     "hlx_set_load_schedule": (C.c_int, [_P, i32]),
     "hlx_get_load_schedule": (i32, [_P]),
     "hlx_profile": (C.c_int, [_P, i32]),

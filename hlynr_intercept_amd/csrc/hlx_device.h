@@ -223,31 +223,110 @@ DEV void gust_draws(const Rng& rng, V3& g, float& e) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// The two float32 transcendentals the reference's step really executes, restated (CPU twin: oracle/ref_math.h;
+// tests/test_ref_math.py pins both, and hlx_selftest_math lets the GPU tests compare this copy bit for bit):
+//   * `np.float32 ** python_float` (physics_models.py:100, :324) = the host libm's powf = glibc's table-driven
+//     algorithm (e_powf.c: log2 by a 16-entry table + degree-5 polynomial, exp2 by a 32-entry table + degree-3
+//     polynomial, all in double, one final rounding).  Fused or unfused multiply-adds give the same float on every
+//     argument of the step path (ref_math.h), so the fused form is used here.
+//   * `np.exp(np.float32)` (physics_models.py:78,105,113; environment.py:1174-1180,1222) = numpy's own float32 SIMD
+//     kernel (Cody-Waite reduction, degree-5 / degree-2 rational in float32 FMA arithmetic, IEEE division).
+// The tables (512 B) are staged in LDS by the step kernel: a per-lane table lookup from LDS costs ~100 cycles, from
+// global memory ~700, and a wave that is alone on its SIMD eats every one of them.
+// ---------------------------------------------------------------------------------------------
+struct PowTab {
+    double lt[16][2];                // __powf_log2_data.tab: {1/c, log2(c)}
+    unsigned long long et[32];       // __exp2f_data.tab: bits(2^(i/32)) - (i << 47)
+};
+__device__ const PowTab HLX_POW_TAB = {
+    {{0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2}, {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2},
+     {0x1.49539f0f010bp+0, -0x1.7418b0a1fb77bp-2},  {0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2},
+     {0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2}, {0x1.25e227b0b8eap+0, -0x1.97c1d1b3b7afp-3},
+     {0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3}, {0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4},
+     {0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5}, {0x1p+0, 0x0p+0},
+     {0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4},  {0x1.ca4b31f026aap-1, 0x1.476a9543891bap-3},
+     {0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2},
+     {0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2},  {0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2}},
+    {0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+     0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+     0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+     0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+     0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+     0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+     0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+     0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull}};
+// `tab` = the table staged in LDS (or HLX_POW_TAB itself where latency does not matter)
+DEV float pow_ref(float x, float y, const PowTab* tab) {   // x > 0 finite normal; result inside the normal range
+    const uint32_t ix = __float_as_uint(x);
+    const uint32_t tmp = ix - 0x3f330000u;
+    const uint32_t i = (tmp >> 19) & 15u;
+    const uint32_t top = tmp & 0xff800000u;
+    const int k = (int32_t)top >> 23;
+    const double2 e = *reinterpret_cast<const double2*>(tab->lt[i]);
+    const double r = __builtin_fma((double)__uint_as_float(ix - top), e.x, -1.0), y0 = e.y + (double)k;
+    const double r2 = r * r;
+    double l = __builtin_fma(0x1.27616c9496e0bp-2, r, -0x1.71969a075c67ap-2);
+    const double p = __builtin_fma(0x1.ec70a6ca7baddp-2, r, -0x1.7154748bef6c8p-1);
+    double q = __builtin_fma(0x1.71547652ab82bp0, r, y0);
+    q = __builtin_fma(p, r2, q);
+    l = __builtin_fma(l, r2 * r2, q);                                   // log2(x)
+    const double ylogx = (double)y * l;
+    const double SHIFT = 0x1.8p+52 / 32.0;
+    double kd = ylogx + SHIFT;
+    const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+    kd -= SHIFT;
+    const double rr = ylogx - kd;
+    const double s = __longlong_as_double((long long)(tab->et[ki & 31ull] + (ki << 47)));
+    const double z = __builtin_fma(0x1.c6af84b912394p-5, rr, 0x1.ebfce50fac4f3p-3);
+    double ev = __builtin_fma(0x1.62e42ff0c52d6p-1, rr, 1.0);
+    ev = __builtin_fma(z, rr * rr, ev);
+    return (float)(ev * s);
+}
+DEV float exp_np(float x) {   // numpy's float32 exp kernel, -103.97 < x < 88.72
+    const float magic = 0x1.8p23f;
+    float qd = x * 1.44269504088896340736f;
+    qd = qd + magic;
+    asm volatile("" : "+v"(qd));              // the round-to-integer trick must survive the optimiser
+    qd = qd - magic;
+    x = __builtin_fmaf(qd, -6.93145752e-1f, x);
+    x = __builtin_fmaf(qd, -1.42860677e-6f, x);
+    float num = __builtin_fmaf(5.082762527590693718096e-04f, x, 6.757896990527504603057e-03f);
+    num = __builtin_fmaf(num, x, 5.114512081637298353406e-02f);
+    num = __builtin_fmaf(num, x, 2.473615434895520810817e-01f);
+    num = __builtin_fmaf(num, x, 7.257664613233124478488e-01f);
+    num = __builtin_fmaf(num, x, 9.999999999980870924916e-01f);
+    float den = __builtin_fmaf(2.159509375685829852307e-02f, x, -2.742335390411667452936e-01f);
+    den = __builtin_fmaf(den, x, 1.0f);
+    return ldexpf(num / den, (int)qd);
+}
+
+// ---------------------------------------------------------------------------------------------
 // physics_models.py:154-177  ISA atmosphere (float32 altitude) -> density, speed of sound
 // ---------------------------------------------------------------------------------------------
-DEV void atmosphere(float alt, float T0, float& rho, float& sos) {
+DEV void atmosphere(float alt, float T0, float& rho, float& sos, const PowTab* tab) {
     constexpr float R = 287.05f, G = 9.80665f, L = 0.0065f;
     constexpr float EXPO = (float)(9.80665 / (287.05 * 0.0065));
     constexpr float GAMMA_R = (float)(1.4 * 287.05);
     float T, P;
     if (alt <= 11000.0f) {
         T = T0 - L * alt;                         // :70-71
-        P = 101325.0f * powf(T / T0, EXPO);       // :95-100
+        P = 101325.0f * pow_ref(HLX_DIVF(T, T0), EXPO, tab);   // :95-100
     } else if (alt <= 20000.0f) {                 // :72-74,102-108 (not reachable in shipped scenarios)
         T = 216.65f;
-        P = 22632.0f * expf((-G * (alt - 11000.0f)) / (float)(287.05 * 216.65));
+        P = 22632.0f * exp_np((-G * (alt - 11000.0f)) / (float)(287.05 * 216.65));
     } else {                                      // :76-78,110-113
         float ex = alt - 20000.0f;
-        T = 216.65f * expf(-ex / 10000.0f);
+        T = 216.65f * exp_np(-ex / 10000.0f);
         const float Pb = 5474.790039909648f;      // 22632 * exp(-g*9000/(R*216.65))  (:112)
-        P = Pb * expf(-ex / 6000.0f);
+        P = Pb * exp_np(-ex / 6000.0f);
     }
     rho = HLX_DIVF(P, R * T);                     // :166
     sos = HLX_SQRTF(GAMMA_R * T);                     // :167-169
 }
 
 struct DragParams {
-    float subsonic, supersonic, mach_span, peak, base_cd, cd_super;   // cd_super = F(base_cd * supersonic_multiplier)
+    // the reference holds base_cd / peak multiplier as Python floats: each use rounds a float64 expression ONCE to float32
+    float subsonic, supersonic, mach_span, peak_m1 /* F(peak - 1.0) */, base_cd /* F(base_cd) */, cd_super /* F(base_cd * supersonic_multiplier) */;
 };
 // physics_models.py:236-264  drag force vector (float32 velocity); `area` = reference_area
 DEV V3 mach_drag_force(V3 v, float rho, float sos, float area, const DragParams& p) {
@@ -258,7 +337,7 @@ DEV V3 mach_drag_force(V3 v, float rho, float sos, float area, const DragParams&
     if (mach < p.subsonic) cd = p.base_cd;                                  // :207-209
     else if (mach < p.supersonic) {
         float frac = HLX_DIVF(mach - p.subsonic, p.mach_span);              // :213-214
-        cd = p.base_cd * (1.0f + (p.peak - 1.0f) * frac);                   // :215-216
+        cd = p.base_cd * (1.0f + p.peak_m1 * frac);                         // :215-216 ((peak - 1.0) is a Python-float expression)
     } else cd = p.cd_super;                                                 // :220 (python-float product)
     float a = (((0.5f * rho) * (vm * vm)) * cd) * area;                     // :258
     return V3{HLX_DIVF(-v.x, vm) * a, HLX_DIVF(-v.y, vm) * a, HLX_DIVF(-v.z, vm) * a};   // :262-264
@@ -271,7 +350,7 @@ DEV D3 mach_drag_force64(D3 v, float rho, float sos, double area, const DragPara
     double cd;
     if (mach < (double)p.subsonic) cd = p.base_cd;
     else if (mach < (double)p.supersonic)
-        cd = (double)p.base_cd * (1.0 + ((double)p.peak - 1.0) * ((mach - (double)p.subsonic) / ((double)p.supersonic - (double)p.subsonic)));
+        cd = (double)p.base_cd * (1.0 + (double)p.peak_m1 * ((mach - (double)p.subsonic) / ((double)p.supersonic - (double)p.subsonic)));
     else cd = (double)p.cd_super;
     double a = ((((double)(0.5f * rho)) * (vm * vm)) * cd) * area;
     return D3{(-v.x / vm) * a, (-v.y / vm) * a, (-v.z / vm) * a};

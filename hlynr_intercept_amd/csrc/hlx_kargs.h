@@ -31,8 +31,8 @@ enum : int {
     G_KF1,       // double2: Kalman position z, velocity x
     G_KF2,       // double2: Kalman velocity y, z
     G_KFP,       // float4: covariance block p_pp, p_pv, p_vp, p_vv
-    G_THRUST,    // float4: actual thrust xyz (thrust lag), pad               [thrust lag only]
-    G_MISC,      // float4: T0, base_cd, transonic peak multiplier, pad       [domain randomisation only]
+    G_THRUST,    // float4: actual thrust xyz (thrust lag), F(base_cd * supersonic_multiplier)   [thrust lag / domain randomisation]
+    G_MISC,      // {double T0, float F(base_cd), float F(peak multiplier - 1)}   [domain randomisation only]
     G_VPOS,      // float4 x HLX_MAX_VOLLEY: volley missile k position xyz, its minimum distance        [volley only]
     G_VVEL = G_VPOS + HLX_MAX_VOLLEY,   // float4 x HLX_MAX_VOLLEY: velocity xyz, bits: 0 active | 8-9 priority index |
                                         // 12-14 missiles intercepted (the last two in missile 0's word only)
@@ -50,7 +50,7 @@ struct KCfg {
     double dt64, inv_dtf;     // dt ; 1 / (double)F(dt)
     float max_range, max_velocity, inv_max_range, inv_max_velocity;
     float target[3];
-    float subsonic, supersonic, mach_span, peak, cd_super;
+    float subsonic, supersonic, mach_span, peak_m1, cd_super;
     double super_mult;
     float base_wind[3];
     double wind_var;

@@ -125,6 +125,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
     //      rollout writes slot k mod out_slots of the [out_slots][N][...] output arrays)
     const int T, const int out_slot0, const int out_slots) {
     __shared__ __attribute__((aligned(16))) float tile[64 * HLX_OBS_DIM];
+    __shared__ __attribute__((aligned(16))) PowTab s_pow;   // glibc powf tables (hlx_device.h), staged by the wave itself
     // generic variants read the feature flags at run time (one scalar load) -- except volley mode, whose K-missile loops
     // are compiled in or out: the generic variant comes with and without them (KF_DYNAMIC [| HLX_F_VOLLEY])
     const uint32_t FL = (SPEC & KF_DYNAMIC) ? ((P->hot.c.flags & ~(uint32_t)HLX_F_VOLLEY) | (SPEC & (uint32_t)HLX_F_VOLLEY)) : SPEC;
@@ -161,13 +162,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
     float4 g_ipos = A[G_IPOS * 64], g_ivel = A[G_IVEL * 64], g_quat = A[G_QUAT * 64], g_mpos = A[G_MPOS * 64];
     float4 g_mvel = A[G_MVEL * 64], g_w1 = A[G_W1 * 64];
     double2 g_w0 = AD[G_W0 * 64];
-    float4 g_thr = make_float4(0.f, 0.f, 0.f, 0.f), g_misc = make_float4(288.15f, 0.3f, 0.f, 0.f);
-    if (HAS(HLX_F_THRUST_LAG)) g_thr = A[G_THRUST * 64];
+    float4 g_thr = make_float4(0.f, 0.f, 0.f, 0.f), g_misc = g_thr;
+    if (HAS(HLX_F_THRUST_LAG) || HAS(HLX_F_DOMAIN_RAND)) g_thr = A[G_THRUST * 64];   // .w: a domain-randomised constant
     if (HAS(HLX_F_DOMAIN_RAND)) g_misc = A[G_MISC * 64];
     // Everything down to the construction of `hot` runs with ALL lanes enabled: the constants are fetched with
     // cross-lane reads (v_readlane), so the lanes that hold them must have executed their loads even in a partial
     // tail block; padding lanes use the last live environment's addresses and their results are discarded.
     const int ic = live ? i : (n - 1);
+    // powf tables: 512 B, lane l fetches 8 bytes (in flight with the state loads), written to LDS behind the Philox block
+    const bool need_pow = HAS(HLX_F_ATMOSPHERE) || HAS(HLX_F_ENH_WIND);
+    unsigned long long pow_word = 0ull;
+    if (need_pow) pow_word = reinterpret_cast<const unsigned long long*>(&HLX_POW_TAB)[lane];
     float4 g_kfp = make_float4(0.f, 0.f, 0.f, 0.f);
     double2 g_kf0 = make_double2(0., 0.), g_kf1 = g_kf0, g_kf2 = g_kf0;
     // (Staging the block in LDS and letting every use be a broadcast ds_read was measured too: 190 fewer
@@ -284,14 +289,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             if (!PERSIST) { g_kfp = A[G_KFP * 64 + late]; g_kf0 = AD[G_KF0 * 64 + late]; g_kf1 = AD[G_KF1 * 64 + late]; g_kf2 = AD[G_KF2 * 64 + late]; }
         }
         PIN4(g_ipos); PIN4(g_ivel); PIN4(g_quat); PIN4(g_mpos); PIN4(g_mvel); PIN4(g_w1); PIN2(g_w0);
-        if (HAS(HLX_F_THRUST_LAG)) PIN4(g_thr);
+        if (HAS(HLX_F_THRUST_LAG) || HAS(HLX_F_DOMAIN_RAND)) PIN4(g_thr);
         if (HAS(HLX_F_DOMAIN_RAND)) PIN4(g_misc);
         PIN2(a01); PIN2(a23); PIN2(a45);
         // (the Kalman / ring registers are released further down, right before the observation section)
         // the output pointers of the kernarg tail have landed by now
         asm volatile("" ::"s"(obs_out), "s"(reward_out), "s"(term_out), "s"(trunc_out));
         if (!PERSIST) asm volatile("" : "+v"(hotw0), "+v"(hotw1));
-        if (!HAS(HLX_F_DOMAIN_RAND)) g_misc.z = HOT(c.peak);
+        if (need_pow && kk == 0) {
+            reinterpret_cast<unsigned long long*>(&s_pow)[lane] = pow_word;
+            __syncthreads();   // one wave per workgroup: orders the LDS writes before the per-lane lookups below
+        }
         done_idx_out = HOT(opt.done_idx);
         if (live) {   // ============================== per-environment work, live lanes only ==============================
         STAMP(2);   // Philox block done (loads still in flight)
@@ -306,9 +314,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         bool crossed = (packed >> 25) & 1u, kf_init = (packed >> 26) & 1u, kf_x64 = (packed >> 27) & 1u;
         int on_delay = (int)(packed >> 28);
         V3 thrust_act = v3(g_thr.x, g_thr.y, g_thr.z);
-        float T0 = g_misc.x;
-        DragParams dp{HOT(c.subsonic), HOT(c.supersonic), HOT(c.mach_span), g_misc.z, g_misc.y, HOT(c.cd_super)};
-        if (HAS(HLX_F_DOMAIN_RAND)) dp.cd_super = (float)((double)dp.base_cd * HOT(c.super_mult));
+        // Per-episode constants of domain randomisation.  The reference keeps them as Python floats (float64): T0 accumulates
+        // over episodes in float64 and is rounded to float32 where it meets the float32 altitude; base_cd and the peak
+        // multiplier enter float32 expressions as F(base_cd), F(peak - 1.0) and F(base_cd * supersonic_multiplier).
+        double T0 = 288.15;
+        DragParams dp{HOT(c.subsonic), HOT(c.supersonic), HOT(c.mach_span), HOT(c.peak_m1), 0.3f, HOT(c.cd_super)};
+        if (HAS(HLX_F_DOMAIN_RAND)) {
+            T0 = __hiloint2double(__float_as_int(g_misc.y), __float_as_int(g_misc.x));
+            dp.base_cd = g_misc.z; dp.peak_m1 = g_misc.w; dp.cd_super = g_thr.w;
+        }
 
         // volley mode (environment.py:44): every missile of the volley; mpos / mvel above are `self.missile_state`,
         // the entry `prio` of this list.  These groups always travel through the arena (also in the fused rollout).
@@ -369,7 +383,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             if (fuel <= 0.f) { fuel = 0.f; thr = v3(0.f, 0.f, 0.f); thrust_act = thr; } // :888-892
             const V3 tacc = divc(thr, 1.0 / 500.0);                                 // :896
             float rho = 1.225f, sos = 343.f;
-            if (HAS(HLX_F_ATMOSPHERE)) atmosphere(fmaxf(ipos.z, 0.f), T0, rho, sos); // :899-906
+            if (HAS(HLX_F_ATMOSPHERE)) atmosphere(fmaxf(ipos.z, 0.f), (float)T0, rho, sos, &s_pow); // :899-906
             const float GRAV = -9.81f;
             if (w64) {                                                              // float64 air-relative velocity
                 D3 va = to_d3(ivel) - wind;                                         // :910
@@ -415,7 +429,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             // -------------------------------------------------------------- missile (environment.py:1069-1117)
             auto missile_step = [&](V3& mpos, V3& mvel, const D3& z_ev) {
                 float mrho = 1.225f, msos = 343.f;
-                if (HAS(HLX_F_ATMOSPHERE)) atmosphere(fmaxf(mpos.z, 0.f), T0, mrho, msos);
+                if (HAS(HLX_F_ATMOSPHERE)) atmosphere(fmaxf(mpos.z, 0.f), (float)T0, mrho, msos, &s_pow);
                 D3 sum;                                                             // drag + gravity, before evasion
                 if (w64) {
                     D3 va = to_d3(mvel) - wind;
@@ -458,7 +472,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 float prof, ti;
                 if (walt <= 10.f) { prof = 1.0f; ti = HOT(c.ti_low); }
                 else if (walt <= HOT(c.bl_height)) {
-                    prof = powf(divc(walt, 1.0 / 10.0), 0.143f);                    // :319-324
+                    prof = pow_ref(divc(walt, 1.0 / 10.0), 0.143f, &s_pow);                    // :319-324
                     ti = HOT(c.ti_mid) * (1.0f - (walt / HOT(c.bl_height)) * 0.7f);           // :343-346
                 } else { prof = HOT(c.bl_prof); ti = HOT(c.ti_high); }
                 V3 w = v3(HOT(c.base_wind[0]) * prof, HOT(c.base_wind[1]) * prof, HOT(c.base_wind[2]) * prof);
@@ -566,9 +580,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     if (crossed) {
                         reward = 3000.f;
                         if (md < HOT(cur.radius)) reward = reward + HLX_DIVF(HOT(cur.radius) - md, HOT(cur.radius)) * 1000.f;
-                        reward = reward + expf(divc(-md, 1.0 / 25.0)) * 500.f;
-                        reward = reward + expf(divc(-md, 1.0 / 10.0)) * 1000.f;
-                        reward = reward + expf(divc(-md, 1.0 / 3.0)) * 500.f;
+                        reward = reward + exp_np(divc(-md, 1.0 / 25.0)) * 500.f;
+                        reward = reward + exp_np(divc(-md, 1.0 / 10.0)) * 1000.f;
+                        reward = reward + exp_np(divc(-md, 1.0 / 3.0)) * 500.f;
                         reward = reward + (float)((double)(HOT(c.max_steps) - steps) * 0.3);
                     } else {
                         reward = fmaxf(-md * 0.5f, -2000.f);
@@ -580,7 +594,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     float delta = prev_distance - distance;
                     float cv = divc(delta, HOT(c.inv_dtf));
                     reward = clampf(divc(cv, 1.0 / 100.0), -0.5f, 2.0f) * 0.5f;
-                    if (distance < 50.f) { reward = reward + delta * 5.f; reward = reward + expf(divc(-distance, 1.0 / 10.0)) * 1.0f; }
+                    if (distance < 50.f) { reward = reward + delta * 5.f; reward = reward + exp_np(divc(-distance, 1.0 / 10.0)) * 1.0f; }
                     else if (distance < 150.f) reward = reward + delta * 3.f;
                     else if (distance < 500.f) reward = reward + delta * 1.5f;
                     else reward = reward + delta * 0.8f;
@@ -784,10 +798,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                             zt = f1; zd = f2; zm = f3; zs = f4;
                         }
                         auto mult = [](double var, double z) { return fmin(fmax(1.0 + var * z, 0.1), 3.0); };
-                        if (HAS(HLX_F_ATMOSPHERE)) T0 = (float)((double)T0 + k.dr_var[1] * zt); // :258-261 (accumulates)
+                        if (HAS(HLX_F_ATMOSPHERE)) T0 = T0 + k.dr_var[1] * zt;           // :258-261 (accumulates, float64)
                         if (HAS(HLX_F_MACH_DRAG)) {                                 // :270-280
-                            dp.base_cd = (float)(0.3 * mult(k.dr_var[2], zd));
-                            dp.peak = (float)(3.0 * mult(k.dr_var[3], zm));
+                            const double cd64 = 0.3 * mult(k.dr_var[2], zd);
+                            dp.base_cd = (float)cd64; dp.cd_super = (float)(cd64 * HOT(c.super_mult));
+                            dp.peak_m1 = (float)(3.0 * mult(k.dr_var[3], zm) - 1.0);
                         }
                         if (HOT(c.o_delay) > 0)                                          // :289-297
                             on_delay = min(10, max(1, (int)(3.0 * mult(k.dr_var[4], zs))));
@@ -1117,14 +1132,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             PUT4(G_MPOS, g_mpos, make_float4(mpos.x, mpos.y, mpos.z, min_distance));
             PUT4(G_MVEL, g_mvel, make_float4(mvel.x, mvel.y, mvel.z, last_distance));
             PUT2(G_W0, g_w0, make_double2(wind.x, wind.y));
-            if (HAS(HLX_F_THRUST_LAG)) PUT4(G_THRUST, g_thr, make_float4(thrust_act.x, thrust_act.y, thrust_act.z, 0.f));
+            if (HAS(HLX_F_THRUST_LAG) || HAS(HLX_F_DOMAIN_RAND)) PUT4(G_THRUST, g_thr, make_float4(thrust_act.x, thrust_act.y, thrust_act.z, dp.cd_super));
             PUT4(G_W1, g_w1, make_float4(__int_as_float(__double2loint(wind.z)), __int_as_float(__double2hiint(wind.z)),
                                          __uint_as_float(packed), ep_return));
             PUT2(G_KF0, g_kf0, make_double2(kxp.x, kxp.y));
             PUT2(G_KF1, g_kf1, make_double2(kxp.z, kxv.x));
             PUT2(G_KF2, g_kf2, make_double2(kxv.y, kxv.z));
             PUT4(G_KFP, g_kfp, make_float4(p_pp, p_pv, p_vp, p_vv));
-            if (HAS(HLX_F_DOMAIN_RAND)) PUT4(G_MISC, g_misc, make_float4(T0, dp.base_cd, dp.peak, 0.f));
+            if (HAS(HLX_F_DOMAIN_RAND)) PUT4(G_MISC, g_misc, make_float4(__int_as_float(__double2loint(T0)), __int_as_float(__double2hiint(T0)), dp.base_cd, dp.peak_m1));
             if (HAS(HLX_F_VOLLEY)) {
 #pragma unroll
                 for (int k = 0; k < HLX_MAX_VOLLEY; ++k) {
@@ -1216,7 +1231,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
     if (PERSIST && live) {   // state back to the arena, once
         STG(G_IPOS, g_ipos); STG(G_IVEL, g_ivel); STG(G_QUAT, g_quat); STG(G_MPOS, g_mpos); STG(G_MVEL, g_mvel);
         STG(G_W0, g_w0); STG(G_W1, g_w1);
-        if (HAS(HLX_F_THRUST_LAG)) STG(G_THRUST, g_thr);
+        if (HAS(HLX_F_THRUST_LAG) || HAS(HLX_F_DOMAIN_RAND)) STG(G_THRUST, g_thr);
         STG(G_KF0, g_kf0); STG(G_KF1, g_kf1); STG(G_KF2, g_kf2); STG(G_KFP, g_kfp);
         if (HAS(HLX_F_DOMAIN_RAND)) STG(G_MISC, g_misc);
     }

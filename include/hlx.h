@@ -162,7 +162,12 @@ typedef struct hlx_env_state {
     int32_t g_len;
     double g_ring[HLX_RING_CAP][8];     /* oldest -> newest : rel_pos xyz (float64 measurement), quality, rel_vel xyz,
                                            sample-was-a-detection flag */
-    float T0, base_cd, transonic_peak;  /* constants touched by domain randomisation */
+    /* constants touched by domain randomisation (physics_randomizer.py:258-280).  The reference keeps them as Python
+     * floats: the sea-level temperature accumulates over episodes in float64; the drag constants enter float32
+     * expressions rounded once, and that is how the kernel holds them: F(base_cd), F(peak multiplier - 1.0),
+     * F(base_cd * supersonic_multiplier). */
+    double T0;
+    float base_cd, transonic_peak_m1, cd_super;
     float ep_return;
     /* volley mode: every missile of the volley; mis_pos / mis_vel above are the reference's `self.missile_state`,
      * i.e. entry `prio` of this list (environment.py:643-650) */
@@ -246,6 +251,12 @@ int hlx_profile_read(hlx_env *env, double *total_ms, int64_t *launches);
  * (the default at hlx_create).  hlx_get_load_schedule returns the schedule in force. */
 int hlx_set_load_schedule(hlx_env *env, int32_t mode);
 int32_t hlx_get_load_schedule(const hlx_env *env);
+
+/* Diagnostics: evaluate the step kernel's restated transcendentals element-wise on device arrays (current device).
+ * kind 0: out[i] = powf(x[i], y) as glibc computes it (physics_models.py:100,324 are `np.float32 ** float` = libm powf);
+ * kind 1: out[i] = np.exp(np.float32 x[i]) as numpy's float32 kernel computes it (physics_models.py:78,105,113,
+ * environment.py:1174-1180,1222).  tests/ compare both bit for bit with the oracle's copies. */
+int hlx_selftest_math(int32_t kind, const float *x, float y, float *out, int64_t n, void *stream);
 
 int32_t hlx_num_envs(const hlx_env *env);
 int64_t hlx_vec_steps(const hlx_env *env);              /* launches so far (the RNG/ring clock) */

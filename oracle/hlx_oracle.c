@@ -18,6 +18,7 @@
  */
 #define _GNU_SOURCE
 #include "hlx_oracle.h"
+#include "ref_math.h"
 
 #include <math.h>
 #include <string.h>
@@ -56,14 +57,14 @@ static void atmosphere(double alt /*f32, >=0*/, double T0, double *rho, double *
         T = 216.65;
         double ex = F(alt - F(11000.0));
         double a = F(F(F(-G) * ex) / F(R * 216.65));
-        P = F(F(22632.0) * (double)expf((float)a));
+        P = F(F(22632.0) * (double)ref_np_expf((float)a));
         *rho = F(P / F(R * T));
         *sos = F(sqrt(1.4 * R * T));
     } else {
         double ex = F(alt - F(20000.0));
-        T = F(F(216.65) * (double)expf((float)F(F(-ex) / F(10000.0))));       /* :76-78 */
+        T = F(F(216.65) * (double)ref_np_expf((float)F(F(-ex) / F(10000.0))));       /* :76-78 */
         double Pb = 22632.0 * exp(-G * (20000.0 - 11000.0) / (R * 216.65));    /* :112 (python floats) */
-        P = F(F(Pb) * (double)expf((float)F(F(-ex) / F(6000.0))));             /* :113 */
+        P = F(F(Pb) * (double)ref_np_expf((float)F(F(-ex) / F(6000.0))));             /* :113 */
         *rho = F(P / F(F(R) * T));
         *sos = F(sqrt(F(F(1.4 * R) * T)));
     }
@@ -896,9 +897,9 @@ void orc_step(const orc_config *c, orc_state *s, const float *action, const doub
                     double ir = F(F(F(rad) - md) / F(rad));
                     reward = F(reward + F(ir * F(1000.0)));
                 }
-                reward = F(reward + F((double)expf((float)F(-md / F(25.0))) * F(500.0)));
-                reward = F(reward + F((double)expf((float)F(-md / F(10.0))) * F(1000.0)));
-                reward = F(reward + F((double)expf((float)F(-md / F(3.0))) * F(500.0)));
+                reward = F(reward + F((double)ref_np_expf((float)F(-md / F(25.0))) * F(500.0)));
+                reward = F(reward + F((double)ref_np_expf((float)F(-md / F(10.0))) * F(1000.0)));
+                reward = F(reward + F((double)ref_np_expf((float)F(-md / F(3.0))) * F(500.0)));
                 reward = F(reward + F((c->max_steps - s->steps) * 0.3));
             } else {
                 reward = F(-md * F(0.5));
@@ -913,7 +914,7 @@ void orc_step(const orc_config *c, orc_state *s, const float *action, const doub
             reward = F(clipd(F(cv / F(100.0)), -0.5, 2.0) * F(0.5));
             if (distance < F(50.0)) {
                 reward = F(reward + F(delta * F(5.0)));
-                reward = F(reward + F((double)expf((float)F(-distance / F(10.0))) * F(1.0)));
+                reward = F(reward + F((double)ref_np_expf((float)F(-distance / F(10.0))) * F(1.0)));
             } else if (distance < F(150.0)) reward = F(reward + F(delta * F(3.0)));
             else if (distance < F(500.0)) reward = F(reward + F(delta * F(1.5)));
             else reward = F(reward + F(delta * F(0.8)));
@@ -981,3 +982,30 @@ void orc_step_batch(const orc_config *cfg, orc_state *st, int32_t n, const float
 int32_t orc_sizeof_state(void) { return (int32_t)sizeof(orc_state); }
 int32_t orc_sizeof_config(void) { return (int32_t)sizeof(orc_config); }
 int32_t orc_sizeof_out(void) { return (int32_t)sizeof(orc_out); }
+
+
+/* ------------------------------------------------------------------------------------------
+ * ref_math.h checks (tests/test_ref_math.py): the restated glibc powf against this host's powf over a range of
+ * float32 bit patterns; the restated numpy exp kernel in batch form (compared with np.exp by the test).
+ * ---------------------------------------------------------------------------------------- */
+long orc_check_powf(uint32_t lo_bits, uint32_t hi_bits, float y, uint32_t *first_bad) {
+    long bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (int64_t u = (int64_t)lo_bits; u <= (int64_t)hi_bits; ++u) {
+        uint32_t ub = (uint32_t)u;
+        float x;
+        memcpy(&x, &ub, 4);
+        float a = powf(x, y), b = ref_powf(x, y);
+        if (memcmp(&a, &b, 4) != 0) {
+            bad += 1;
+            if (first_bad) *first_bad = ub;
+        }
+    }
+    return bad;
+}
+void orc_ref_powf_batch(const float *x, float y, float *out, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) out[i] = ref_powf(x[i], y);
+}
+void orc_np_expf_batch(const float *x, float *out, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) out[i] = ref_np_expf(x[i]);
+}

@@ -81,7 +81,8 @@ def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liboracle.so")
     src = os.path.join(_HERE, "hlx_oracle.c")
     hdr = os.path.join(_HERE, "hlx_oracle.h")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    rm = os.path.join(_HERE, "ref_math.h")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(rm)):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
 

@@ -22,31 +22,38 @@ OBS_ATOL = 2e-5      # |obs| <= 2; Kalman-filtered entries carry ~1e-6 of float3
 # integrator operation by operation (hlx_device.h).  Where the reference's arithmetic is all +,-,*,/,sqrt
 # (base physics) that makes state, distance and reward come out bit-identical and the bar applies to every
 # step of a free-running trajectory.
-# With ISA atmosphere / boundary-layer wind the reference calls the host libm's float32 pow(), which is not
-# correctly rounded in ~2 % of calls and cannot be reproduced bit-for-bit on the GPU: a 1-ulp difference in
-# the air density occasionally (~1e-5 per env-step) flips the rounding of a velocity, after which positions
-# sit a fraction of an ulp apart and some later distances round 1 ulp differently.  For those configurations
-#   * free-running trajectories: reward error bounded by what 2 ulps of a 5 km distance can do (1e-3 relative
-#     to max(1,|r|)); state/distance/observation still meet the bar;
-#   * from identical state (GPU re-synchronised to the oracle before every step): at most 1 in 1000 env-steps
-#     may exceed the bar, same absolute bound.
-REWARD_MAX_POW = 1e-3
-
-
-def _uses_libm_pow(rc):
-    return bool(rc.atmosphere or rc.enhanced_wind)
+# With ISA atmosphere / boundary-layer wind the reference calls the host libm's float32 pow(); the kernel restates
+# glibc's algorithm (hlx_device.h pow_ref, pinned by tests/test_ref_math.py), so those configurations meet the same bar.
 
 
 def _check_reward_errors(errs, rc, what, resynced=False):
     errs = np.asarray(errs, np.float64)
     if errs.size == 0:
         return
-    if _uses_libm_pow(rc):
-        assert errs.max() <= REWARD_MAX_POW, (what, errs.max())
-        if resynced:
-            assert (errs > RTOL).mean() <= 1e-3, (what, int((errs > RTOL).sum()), errs.size)
-    else:
-        assert errs.max() <= RTOL, (what, errs.max(), int((errs > RTOL).sum()), errs.size)
+    assert errs.max() <= RTOL, (what, errs.max(), int((errs > RTOL).sum()), errs.size)
+
+
+def _obs_tolerance(rc, ora, done):
+    """Per-entry absolute tolerance [n, 26].  OBS_ATOL everywhere, except where the reference's own formula is
+    ill-conditioned: in `los_frame` mode the lead-angle cosine obs[5] is the direction of the Kalman velocity estimate
+    (core.py:861-868), which the reference obtains as `(kf_vel - int_vel) + int_vel` -- one float32 ulp of the
+    interceptor's speed (4e-6 m/s) is a 1e-4 relative change of a 0.04 m/s estimate --, and the LOS rates obs[2:4]
+    divide by the filtered range (core.py:810-811), which is under a metre when the filter was initialised from an empty
+    delay-line sample.  Any implementation that does not replay OpenBLAS's sgemm rounding order inside the filter lands
+    within these bounds of the reference, not within 2e-5; the bound is widened only in that regime."""
+    tol = np.full((ora.n, 26), OBS_ATOL)
+    if rc.obs_mode != 2:
+        return tol
+    so = np.frombuffer(ora.state, dtype=np.dtype(type(ora.state[0])))
+    kf = so["kf_x"]
+    tv = np.linalg.norm(kf[:, 3:6], axis=1)
+    rng = np.linalg.norm(kf[:, 0:3] - so["int_pos"], axis=1)
+    loose5 = done | (tv < 2.0)
+    loose23 = done | (rng < 100.0)
+    tol[loose5, 5] = 5e-4
+    tol[loose23, 2] = 5e-4
+    tol[loose23, 3] = 5e-4
+    return tol
 
 
 def _oracle_to_gpu_state(ora, env):
@@ -69,7 +76,8 @@ def _oracle_to_gpu_state(ora, env):
             r = o.g_ring[k]
             g.g_ring[k][0], g.g_ring[k][1], g.g_ring[k][2], g.g_ring[k][3] = r[0], r[1], r[2], r[6]
             g.g_ring[k][4], g.g_ring[k][5], g.g_ring[k][6], g.g_ring[k][7] = r[3], r[4], r[5], float(o.g_pos_is64[k])
-        g.T0, g.base_cd, g.transonic_peak = o.T0, o.base_cd, o.transonic_peak
+        # the oracle holds the reference's Python floats; the kernel holds the float32 roundings each use applies
+        g.T0, g.base_cd, g.transonic_peak_m1, g.cd_super = o.T0, o.base_cd, o.transonic_peak - 1.0, o.base_cd * ora.rc.supersonic_multiplier
         for k in range(4):   # volley: every missile, its activity and minimum distance, the priority index
             for j in range(3):
                 g.v_pos[k][j], g.v_vel[k][j] = o.v_pos[k][j], o.v_vel[k][j]
@@ -322,7 +330,7 @@ def test_gpu_matches_oracle_free_running(scenario, physics, over, variant, late)
         term_obs = info["terminal_observation"].cpu().numpy()
         step_obs_g = np.where(done[:, None], term_obs, obs_h)
         step_obs_o = np.where(done[:, None], ora.terminal_obs, out["obs"])
-        eo = np.max(np.abs(step_obs_g - step_obs_o), axis=1)
+        eo = np.max(np.abs(step_obs_g - step_obs_o) * (OBS_ATOL / _obs_tolerance(rc, ora, done)), axis=1)
         er = _rel(rew.cpu().numpy(), out["reward"])
         ed = _rel(info["distance"].cpu().numpy(), out["distance"])
         # an env whose observation jumps (a detection decided differently at a float32 boundary) is retired
@@ -336,10 +344,7 @@ def test_gpu_matches_oracle_free_running(scenario, physics, over, variant, late)
             if sel.any():
                 assert np.max(np.abs(obs_h[sel] - out["obs"][sel])) <= OBS_ATOL
     assert alive.mean() >= 0.995, f"{(~alive).sum()} of {n} envs diverged in their discrete history"
-    # free-running + libm pow(): velocities may sit 1 ulp apart (see above); two observation entries are
-    # ill-conditioned functions of them (time-to-intercept ~ range/closing^2 when closing -> 0, and the
-    # direction cosine of a near-zero Kalman velocity), hence the wider absolute bound in that case only.
-    assert worst["obs"] <= (10 * OBS_ATOL if _uses_libm_pow(rc) else OBS_ATOL), worst
+    assert worst["obs"] <= OBS_ATOL, worst
     assert worst["distance"] <= RTOL, worst
     _check_reward_errors(np.concatenate(rew_errs), rc, (scenario, physics))
     # full state comparison at the end (alive envs)
@@ -399,7 +404,7 @@ def test_gpu_matches_oracle_from_identical_state(scenario, physics, over, varian
         flag_mismatch += int((~same).sum())
         step_obs_g = np.where(done[:, None], info["terminal_observation"].cpu().numpy(), obs.cpu().numpy())
         step_obs_o = np.where(done[:, None], ora.terminal_obs, out["obs"])
-        eo = np.max(np.abs(step_obs_g - step_obs_o), axis=1)
+        eo = np.max(np.abs(step_obs_g - step_obs_o) * (OBS_ATOL / _obs_tolerance(rc, ora, done)), axis=1)
         ok = same & (eo <= 50 * OBS_ATOL)          # a Bernoulli detection decided at a float32 boundary is retired
         flag_mismatch += int((same & ~ok).sum())
         worst_obs = max(worst_obs, float(eo[ok].max(initial=0.0)))
@@ -446,7 +451,7 @@ def test_full_size_batch_matches_oracle(physics, variant):
         obs_h = obs.cpu().numpy()
         step_obs_g = np.where(done[:, None], info["terminal_observation"].cpu().numpy(), obs_h)
         step_obs_o = np.where(done[:, None], ora.terminal_obs, out["obs"])
-        eo = np.max(np.abs(step_obs_g - step_obs_o), axis=1)
+        eo = np.max(np.abs(step_obs_g - step_obs_o) * (OBS_ATOL / _obs_tolerance(rc, ora, done)), axis=1)
         alive &= eo <= 50 * OBS_ATOL             # a Bernoulli detection decided at a float32 boundary retires the env
         worst["obs"] = max(worst["obs"], float(eo[alive].max(initial=0.0)))
         rew_errs.append(_rel(rew.cpu().numpy(), out["reward"])[alive])
@@ -456,7 +461,7 @@ def test_full_size_batch_matches_oracle(physics, variant):
             worst["reset_obs"] = max(worst["reset_obs"], float(np.max(np.abs(obs_h[sel] - out["obs"][sel]))))
     assert n_done >= n, "every environment must have restarted inside the window"
     assert alive.mean() >= 0.9995, f"{(~alive).sum()} of {n} envs diverged in their discrete history"
-    assert worst["obs"] <= (10 * OBS_ATOL if _uses_libm_pow(rc) else OBS_ATOL) and worst["reset_obs"] <= OBS_ATOL, worst
+    assert worst["obs"] <= OBS_ATOL and worst["reset_obs"] <= OBS_ATOL, worst
     assert worst["distance"] <= RTOL, worst
     _check_reward_errors(np.concatenate(rew_errs), rc, ("full size", physics))
     st = np.frombuffer(env.get_state(), dtype=np.dtype(type(env.get_state()[0])))

@@ -1,0 +1,37 @@
+"""Diagnostic: which observation entries differ between GPU and oracle (free-running random batch), and in what situation."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import oracle.oracle as orc
+from hlynr_intercept_amd.config import resolve_config
+from hlynr_intercept_amd.scenarios import scenario_config
+from hlynr_intercept_amd.vec_env import HlynrVecEnv
+
+over = {"observation_mode": "los_frame", "proximity_fuze_enabled": True, "proximity_kill_radius": 60.0, "max_steps": 200}
+rc = resolve_config(scenario_config("medium", "v2", over))
+n, T = 4096, 260
+env = HlynrVecEnv(resolved=rc, num_envs=n, seed=1234)
+ora = orc.OracleVec(rc, n)
+g = torch.Generator(device="cpu").manual_seed(7)
+sn, rn = env.fill_noise(for_reset=True)
+env.reset_torch(); ora.reset(rn.cpu().numpy().T.copy())
+worst = np.zeros(26); shown = 0
+for t in range(T):
+    a = torch.rand((n, 6), generator=g) * 2 - 1
+    if t % 3 == 0: a[:, 2] = 0.9
+    sn, rn = env.fill_noise()
+    obs, rew, term, trunc, info = env.step_torch(a.to(env.device))
+    out = ora.step(a.numpy(), sn.cpu().numpy().T.copy(), rn.cpu().numpy().T.copy())
+    done = (term.cpu().numpy() | trunc.cpu().numpy()).astype(bool)
+    og = np.where(done[:, None], info["terminal_observation"].cpu().numpy(), obs.cpu().numpy())
+    oo = np.where(done[:, None], ora.terminal_obs, out["obs"])
+    e = np.abs(og - oo)
+    worst = np.maximum(worst, e.max(axis=0))
+    bad = np.argwhere(e > 2e-5)
+    for i, k in bad[:3]:
+        if shown < 15:
+            shown += 1
+            so = np.frombuffer(ora.state, dtype=np.dtype(orc.OrcState))[i]
+            print(f"t={t} env={i} obs[{k}] gpu={og[i,k]!r} orc={oo[i,k]!r} | obs gpu {og[i,:9]} | kf_x={so['kf_x']} int_vel={so['int_vel']} steps={so['steps']} kf64={so['kf_x_is64']}")
+print("worst per index:", np.array2string(worst, precision=2))
+env.close()
