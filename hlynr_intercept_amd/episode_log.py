@@ -110,19 +110,18 @@ def radar_debug(rc, beam_width: float, int_pos, mis_pos, quat, ground_quality: f
 
 
 def _plain(obj):
-    """JSON-ready copy (what logger.py:19-57 does for numpy scalars / arrays / containers)."""
+    """JSON-ready copy, value for value what logger.py:19-57 produces: containers recursively, numpy arrays as lists,
+    numpy scalars as their Python value, a Python float NaN / inf as null (numpy-scalar NaNs stay NaN there too)."""
     if isinstance(obj, dict):
-        return {str(k): _plain(v) for k, v in obj.items()}
+        return {k: _plain(v) for k, v in obj.items()}
     if isinstance(obj, (list, tuple)):
         return [_plain(v) for v in obj]
+    if isinstance(obj, np.generic):
+        return obj.item()
     if isinstance(obj, np.ndarray):
         return obj.tolist()
-    if isinstance(obj, np.bool_):
-        return bool(obj)
-    if isinstance(obj, np.integer):
-        return int(obj)
-    if isinstance(obj, np.floating):
-        return float(obj)
+    if isinstance(obj, float) and (obj != obj or obj in (float("inf"), float("-inf"))):
+        return None
     return obj
 
 

@@ -115,3 +115,34 @@ def test_vec_recorder_writes_one_file_per_episode(tmp_path):
                                         "missiles_intercepted", "volley_size"}                  # inference.py:606-614
     rows0 = _read(os.path.join(rec._logs[0].log_dir, "episodes", "ep_0000.jsonl"))
     assert len([r for r in rows0 if r["type"] == "state"]) == 21 and rows0[-1]["type"] == "state"   # still running
+
+
+def test_episode_files_equal_the_ones_the_references_logger_writes(tmp_path):
+    """tests/golden/logs/*.jsonl were written by the reference's own `UnifiedLogger` (logger.py:148-288) from the scripted
+    session of tests/log_script.py under a deterministic clock (tests/golden/make_log_golden.py).  `EpisodeLog`, fed the
+    same session, must produce the same files BYTE FOR BYTE: record order, key order, flush boundaries, relative
+    timestamps, numpy -> JSON conversion, NaN / inf -> null."""
+    import hlynr_intercept_amd.episode_log as el
+    from tests.log_script import FakeTime, session
+
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "logs")
+    log = EpisodeLog(str(tmp_path), run_name="golden")
+    real_time = el.time
+    el.time = FakeTime()
+    try:
+        for method, kw in session():
+            if method == "log_metrics":
+                log.log_metrics(kw["metrics"])
+            else:
+                getattr(log, method)(**kw)
+    finally:
+        el.time = real_time
+    mine = {"episodes_" + f: os.path.join(log.log_dir, "episodes", f) for f in os.listdir(os.path.join(log.log_dir, "episodes"))}
+    mine["metrics.jsonl"] = log.metrics_file
+    assert sorted(mine) == sorted(os.listdir(golden))
+    for name, path in mine.items():
+        with open(path) as a, open(os.path.join(golden, name)) as b:
+            la, lb = a.read().splitlines(), b.read().splitlines()
+        assert len(la) == len(lb), name
+        for k, (x, y) in enumerate(zip(la, lb)):
+            assert x == y, (name, k, x[:200], y[:200])
