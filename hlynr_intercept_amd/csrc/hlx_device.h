@@ -369,9 +369,13 @@ DEV D3 nan_guard(D3 a, double lim) {
 struct Quat {
     float w, x, y, z;
 };
-DEV V3 forward_vec(Quat q) {   // core.py:1143-1152 (feeds a threshold compare and pure outputs: fast float32)
+DEV V3 forward_vec(Quat q) {   // core.py:1143-1152 (pure outputs and the fast half of the beam test: fast float32)
     V3 f = v3(2.f * (q.x * q.z + q.w * q.y), 2.f * (q.y * q.z - q.w * q.x), 1.f - 2.f * (q.x * q.x + q.y * q.y));
     return f * __builtin_amdgcn_rcpf(fnorm_out(f) + 1e-6f);
+}
+DEV V3 forward_vec_exact(Quat q) {   // the same, operation by operation as the reference: decides beam-edge cases (core.py:546-553)
+    V3 f = v3(2.f * (q.x * q.z + q.w * q.y), 2.f * (q.y * q.z - q.w * q.x), 1.f - 2.f * (q.x * q.x + q.y * q.y));
+    return f / (snorm3(f) + 1e-6f);
 }
 DEV V3 right_vec(Quat q) {     // core.py:1155-1164
     V3 f = v3(1.f - 2.f * (q.y * q.y + q.z * q.z), 2.f * (q.x * q.y + q.w * q.z), 2.f * (q.x * q.z - q.w * q.y));

@@ -841,13 +841,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 STAMP2(3);  // close-up: range
                 const V3 fwd = forward_vec(q);
                 STAMP2(4);  // close-up: forward vector
-                {   // :546-553  arccos(clip(fwd . to_missile)) > half_beam  <=>  clip(fwd . to_missile) < cos(half_beam)
-                    const float cb = clampf(fdot(fwd, rel) * __builtin_amdgcn_rcpf(range + 1e-6f), -1.f, 1.f);
-                    if (on_det && cb < HOT(cur.cos_half_beam)) { on_det = false; on_why = -2.f; }
+                {   // :546-553  arccos(clip(fwd . to_missile)) > half_beam  <=>  clip(fwd . to_missile) < c*, where c* is the
+                    // float32 at which the host's acosf crosses half_beam (found by bisection in hlx_host.inc): the argument is
+                    // formed with the reference's own float32 operations, so the DECISION is the reference's, bit for bit
+                    // Fast arithmetic decides unless the argument is within 1e-5 of c* (ten times the fast path's error bound):
+                    // only then -- about one env-step in 1e5 -- is the reference's operation order replayed.
+                    const float cthr = HOT(cur.cos_half_beam);
+                    float cb = clampf(fdot(fwd, rel) * __builtin_amdgcn_rcpf(range + 1e-6f), -1.f, 1.f);
+                    if (on_det && fabsf(cb - cthr) < 1e-5f) cb = clampf(sdot3(forward_vec_exact(q), rel / (range + 1e-6f)), -1.f, 1.f);
+                    if (on_det && cb < cthr) { on_det = false; on_why = -2.f; }
                 }
                 STAMP2(5);  // close-up: beam angle (acosf)
                 if (on_det) {                                                       // :559-566
                     float aq = (HOT(c.radar_quality) * (1.0f - (range * HOT(c.inv_radar_range)) * 0.5f)) * HOT(cur.on_rel);
+                    if (fabsf(n_on - aq) < 2e-6f)   // Bernoulli draw within a few ulps of the probability: the reference's own division
+                        aq = (HOT(c.radar_quality) * (1.0f - HLX_DIVF(range, HOT(c.radar_range)) * 0.5f)) * HOT(cur.on_rel);
                     if (n_on > aq) { on_det = false; on_why = -3.f; }
                 }
                 STAMP2(6);  // close-up: Bernoulli
@@ -872,15 +880,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 const V3 gp = v3(HOT(c.ground_pos[0]), HOT(c.ground_pos[1]), HOT(c.ground_pos[2]));
                 if (HAS(HLX_F_GROUND)) {
                     V3 g2m = mpos - gp;
+                    // fast float32 first; the reference's own operations where a decision is within reach of the fast path's error
                     float grange = fnorm(g2m);
+                    if (fabsf(grange - HOT(c.g_max_range)) < 0.05f) grange = snorm3(g2m);
                     g_det = !(grange > HOT(c.g_max_range));                              // :396
-                    if (g_det && grange > 1e-6f) {                                  // :401-406  asin is monotonic: compare sines
-                        const float se = clampf(g2m.z * __builtin_amdgcn_rcpf(grange), -1.f, 1.f);
+                    if (g_det && grange > 1e-6f) {                                  // :401-406  arcsin(s) against the elevation window:
+                        // s against the float32 values at which the host's asinf crosses the two limits (hlx_host.inc)
+                        float se = clampf(g2m.z * __builtin_amdgcn_rcpf(grange), -1.f, 1.f);
+                        if (fminf(fabsf(se - HOT(c.sin_min_elev)), fabsf(se - HOT(c.sin_max_elev))) < 4e-6f)
+                            se = clampf(HLX_DIVF(g2m.z, snorm3(g2m)), -1.f, 1.f);
                         if (se < HOT(c.sin_min_elev) || se > HOT(c.sin_max_elev)) g_det = false;
                     }
                     if (mpos.z < 50.f) g_det = false;                               // :409
                     if (g_det) {                                                    // :413-418
                         float dpq = ((HOT(c.g_base_q) * (1.0f - (grange * HOT(c.inv_g_max_range)) * 0.4f)) * HOT(c.weather)) * HOT(cur.g_rel);
+                        if (fabsf(n_g - dpq) < 2e-6f)
+                            dpq = ((HOT(c.g_base_q) * (1.0f - HLX_DIVF(snorm3(g2m), HOT(c.g_max_range)) * 0.4f)) * HOT(c.weather)) * HOT(cur.g_rel);
                         if (n_g > dpq) g_det = false;
                         else {
                             // :422-429 float64 measurement (kept float64 through the delay ring: the Kalman
