@@ -106,6 +106,7 @@ SYMBOLS = {
     "hlx_num_envs": (i32, [_P]),
     "hlx_vec_steps": (i64, [_P]),
     "hlx_kernel_variant": (C.c_char_p, [_P]),
+    "hlx_kernel_baked": (C.c_char_p, [_P]),
     "hlx_sizeof_config": (i32, []),
     "hlx_sizeof_env_state": (i32, []),
     "hlx_last_error": (C.c_char_p, []),

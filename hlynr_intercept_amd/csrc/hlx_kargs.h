@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/hlx.h"
+#include "hlx_kcfg.h"
 
 namespace hlx {
 
@@ -40,36 +41,6 @@ enum : int {
 };
 // ground ring slot: double2 {rel_pos x, y}, {double rel_pos z, float quality, float sample-was-a-detection}, float4 {rel_vel xyz, pad}
 constexpr int GROUND_RING_WORDS16 = 3;
-
-// Per-step ("hot") constants: ride in the kernel-argument block and end up in SGPRs.
-struct KCfg {
-    uint32_t flags;
-    int32_t max_steps, g_delay, o_delay, o_cap;
-    int32_t volley_k;         // missiles per episode (volley mode), else 0
-    float dt;                 // F(dt)
-    double dt64, inv_dtf;     // dt ; 1 / (double)F(dt)
-    float max_range, max_velocity, inv_max_range, inv_max_velocity;
-    float target[3];
-    float subsonic, supersonic, mach_span, peak_m1, cd_super;
-    double super_mult;
-    float base_wind[3];
-    double wind_var;
-    float bl_height, bl_prof, ti_low, ti_mid, ti_high;
-    double turb_lp, gust_scale, inv_tau;
-    float kill_radius, radar_quality, radar_range, inv_radar_range;
-    double radar_quality64;
-    float ground_pos[3], g_max_range, inv_g_max_range, g_base_q, max_datalink, inv_max_datalink, weather;
-    float sin_min_elev, sin_max_elev;   // elevation window as sines (asin is monotonic)
-    double g_range_acc, g_vel_acc, packet_loss;
-    float q11, q12, q22;      // Kalman process noise (core.py:34-42, q = 5^2)
-};
-// Spawn / domain-randomisation ("cold") constants: only finished environments read them, so they live
-// in device memory behind a pointer instead of occupying ~90 SGPRs of every wave.
-struct KCold {
-    double mis_lo[3], mis_span[3], mis_radius[2], mis_az[2], mis_el[2], mis_speed[2];
-    double int_lo[3], int_span[3], ivel_lo[3], ivel_span[3], int_speed[2];
-    double dr_var[5];
-};
 
 // ---------------------------------------------------------------------------------------------------
 // Kernel arguments.  The kernarg segment of a launch is freshly written memory: a scalar load from it misses

@@ -27,6 +27,7 @@
 #include "../../include/hlx.h"
 #include "hlx_device.h"
 #include "hlx_kargs.h"
+#include "hlx_baked_gen.h"
 
 using namespace hlx;
 
@@ -89,8 +90,25 @@ template <> struct HotRd<double> { static DEV double get(uint32_t w0, uint32_t w
 template <typename P> struct HotRd<P*> { static DEV P* get(uint32_t w0, uint32_t w1, int off) {
     const unsigned long long lo = HotRd<uint32_t>::get(w0, w1, off), hi = HotRd<uint32_t>::get(w0, w1, off + 4);
     return reinterpret_cast<P*>(lo | (hi << 32)); } };
+// BAKED instantiations (template parameter BAKE = 1 + index into HLX_BAKED_TAB, hlx_baked_gen.h): the configuration
+// constants (KHot::c) of a shipped scenario preset are compile-time literals -- no cross-lane fetch, no SGPR hazard
+// wait states, and the optimiser folds what depends on them; curriculum scalars and optional-buffer pointers, which can
+// change between launches, still come from the hot words.  hlx_create selects a baked instantiation only when the KCfg
+// it derives equals the table byte for byte.
+template <typename T> struct BakedRd;
+template <> struct BakedRd<float> { static constexpr float get(const uint32_t* t, int off) { return __builtin_bit_cast(float, t[off >> 2]); } };
+template <> struct BakedRd<int32_t> { static constexpr int32_t get(const uint32_t* t, int off) { return (int32_t)t[off >> 2]; } };
+template <> struct BakedRd<uint32_t> { static constexpr uint32_t get(const uint32_t* t, int off) { return t[off >> 2]; } };
+template <> struct BakedRd<double> { static constexpr double get(const uint32_t* t, int off) {
+    return __builtin_bit_cast(double, (unsigned long long)t[off >> 2] | ((unsigned long long)t[(off >> 2) + 1] << 32)); } };
+template <int BAKE, typename T, int OFF> DEV T hot_get(uint32_t w0, uint32_t w1) {
+    if constexpr (BAKE != 0 && OFF < (int)sizeof(KCfg)) {
+        constexpr T v = BakedRd<T>::get(HLX_BAKED_TAB[BAKE - 1], OFF);
+        return v;
+    } else return HotRd<T>::get(w0, w1, OFF);
+}
 #define HOT(path) \
-    (HotRd<std::remove_cv_t<std::remove_reference_t<decltype(((const KHot*)nullptr)->path)>>>::get(hotw0, hotw1, (int)offsetof(KHot, path)))
+    (hot_get<BAKE, std::remove_cv_t<std::remove_reference_t<decltype(((const KHot*)nullptr)->path)>>, (int)offsetof(KHot, path)>(hotw0, hotw1))
 
 // NOISE = parity-mode instantiation that can take its random draws from caller-supplied float64 buffers;
 // the production instantiation (NOISE = false) contains no trace of that path.
@@ -101,7 +119,7 @@ template <typename P> struct HotRd<P*> { static DEV P* get(uint32_t w0, uint32_t
 // LATE = instantiation for small batches (<= two 64-env waves per SIMD): the Kalman groups and the delayed ring sample are
 // loaded as a second batch after the Philox block instead of at kernel entry (see below; a run-time switch was tried
 // and lost both ways -- the optimiser merges the two load sites).
-template <uint32_t SPEC, int MODE /*0 = step, 1 = reset-only*/, bool NOISE, bool PERSIST = false, bool LATE = false>
+template <uint32_t SPEC, int MODE /*0 = step, 1 = reset-only*/, bool NOISE, bool PERSIST = false, bool LATE = false, int BAKE = 0>
 // The parity (NOISE) and reset-only (MODE 1) instantiations never run at a size where occupancy matters: they get the
 // whole register file, hence no scratch spills (see tools/check_hot_words.py for why a spilled hot word is fatal).
 #ifndef HLX_WAVES_PER_EU

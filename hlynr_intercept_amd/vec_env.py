@@ -269,6 +269,11 @@ class HlynrVecEnv(_SB3VecEnv):
             raise RuntimeError("kernel_variant: the environment is closed")
         return self._lib.hlx_kernel_variant(self._h).decode()
 
+    @property
+    def kernel_baked(self) -> str:
+        """Shipped preset whose constants this handle's step launches carry as literals ('' = fetched at run time)."""
+        return self._lib.hlx_kernel_baked(self._h).decode()
+
     # ------------------------------------------------------------------ torch / gymnasium-vector style API
     def reset_torch(self, mask=None, obs_ptr: Optional[int] = None):
         """Reset all envs (or those where `mask` is non-zero); returns the device obs tensor [N, 26].

@@ -260,6 +260,10 @@ int hlx_selftest_math(int32_t kind, const float *x, float y, float *out, int64_t
 
 int32_t hlx_num_envs(const hlx_env *env);
 int64_t hlx_vec_steps(const hlx_env *env);              /* launches so far (the RNG/ring clock) */
+/* Name of the shipped scenario preset whose constants the step launches of this handle carry as compile-time literals
+ * ("medium/base", ...; hlynr_intercept_amd/build.py BAKED), or "" when the configuration is not one of them and the
+ * constants are fetched at run time.  Same arithmetic either way. */
+const char *hlx_kernel_baked(const hlx_env *env);
 const char *hlx_kernel_variant(const hlx_env *env);     /* "base", "v2", "v2dr", "config", "config-easy", "config-volley", "generic" or "generic-volley" */
 int32_t hlx_sizeof_config(void);
 int32_t hlx_sizeof_env_state(void);

@@ -371,3 +371,53 @@ def test_both_load_schedules_give_identical_bits(physics, over):
     a_env.set_load_schedule(-1)
     assert a_env.load_schedule == 1                                         # 777 envs: small batch
     a_env.close(); b_env.close()
+
+
+def _baked_presets():
+    from hlynr_intercept_amd.build import BAKED
+    return BAKED
+
+
+@pytest.mark.parametrize("name,scenario,physics,over", _baked_presets(), ids=[b[0] for b in _baked_presets()])
+def test_baked_presets_are_selected_and_equal_the_runtime_constant_path(name, scenario, physics, over):
+    """The shipped scenario presets run step-kernel instantiations whose configuration constants are compile-time literals
+    (hlx_baked_gen.h).  hlx_create must select them for exactly those configurations, and they must reproduce the ordinary
+    instantiation (constants fetched at run time; forced with HLX_NO_BAKED) bit for bit -- outputs, terminal observations and
+    the full state -- in both load schedules and through the fused rollout.  Any override drops back to the ordinary path."""
+    import os
+    import torch
+    from hlynr_intercept_amd.scenarios import scenario_config
+    from hlynr_intercept_amd.vec_env import HlynrVecEnv
+    n, T = 700, 260
+    cfg = scenario_config(scenario, physics, over)
+    baked = HlynrVecEnv(cfg, num_envs=n, seed=31)
+    assert baked.kernel_baked == name
+    os.environ["HLX_NO_BAKED"] = "1"
+    try:
+        plain = HlynrVecEnv(cfg, num_envs=n, seed=31)
+    finally:
+        del os.environ["HLX_NO_BAKED"]
+    assert plain.kernel_baked == "" and plain.kernel_variant == baked.kernel_variant
+    other = HlynrVecEnv(scenario_config(scenario, physics, dict(over or {}, max_steps=1999)), num_envs=8, seed=31)
+    assert other.kernel_baked == ""
+    other.close()
+    assert torch.equal(baked.reset_torch(), plain.reset_torch())
+    g = torch.Generator(device=baked.device).manual_seed(8)
+    # start mid-episode states that reach every branch quickly: a few hundred steps of a fused rollout on both
+    tape = torch.rand((64, n, 6), generator=g, device=baked.device) * 2 - 1
+    for env in (baked, plain):
+        env.set_rollout_fused(32)
+        for _ in range(12):
+            env.rollout_torch(tape, 2)
+        env.set_rollout_fused(1)
+    assert bytes(baked.get_state()) == bytes(plain.get_state())
+    for t in range(T):
+        if t == T // 2:
+            baked.set_load_schedule(0); plain.set_load_schedule(0)
+        act = torch.rand((n, 6), generator=g, device=baked.device) * 2 - 1
+        ra, rb = baked.step_torch(act), plain.step_torch(act)
+        for x, y in zip(ra[:4], rb[:4]):
+            assert torch.equal(x, y), t
+        assert torch.equal(ra[4]["terminal_observation"], rb[4]["terminal_observation"])
+    assert bytes(baked.get_state()) == bytes(plain.get_state())
+    baked.close(); plain.close()
