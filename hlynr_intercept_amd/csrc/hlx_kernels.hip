@@ -704,9 +704,60 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             // loop-invariant values, and without it the optimiser hoists all six Philox chains (and the float64
             // spawn trigonometry) out of the loop, i.e. executes them on EVERY step for every environment.
             uint32_t rsalt = 0;
+            // Respawn draws: item j = Philox stream `8 + j` (j < 8: spawn uniforms x3, first-observation uniforms, ground
+            // position / velocity normals, two domain-randomisation normal quads) or `13 + j` (j = 8..10: volley missiles 1..3).
+            // A finished lane needs up to eleven Philox evaluations; its wave has 63 other lanes with nothing to do in this
+            // pass, so the WAVE evaluates them: for one finished lane at a time, lane j computes item j of that lane's
+            // counter, and the finished lane picks the results up with v_readlane -- one Philox evaluation (+ one Box-Muller
+            // pair) per finished lane instead of eleven in a row on the launch's critical tail.  Same keys and counters as
+            // the per-lane form (kept for partial tail blocks and the parity instantiation), hence the same draws.
+            constexpr int RS_ITEMS = 11;
+            float rd[RS_ITEMS][4];
+#pragma unroll
+            for (int j = 0; j < RS_ITEMS; ++j) rd[j][0] = rd[j][1] = rd[j][2] = rd[j][3] = 0.f;
             if (pass == 1) {
-                if (__ballot(done) == 0ull) break;
+                const unsigned long long dmask = __ballot(done);
+                if (dmask == 0ull) break;
                 asm volatile("" : "+v"(rsalt));
+                const bool wide = (n - (int)blockIdx.x * 64) >= 64;      // every lane of the wave is live: all can serve
+                if (!rnoise_buf) {
+                    if (wide) {
+                        unsigned long long m = dmask;
+                        while (m) {
+                            const int d = __builtin_ctzll(m);
+                            m &= m - 1ull;
+                            const unsigned long long gd = (unsigned long long)(env_offset + (long long)blockIdx.x * 64 + d);
+                            const Rng rw{rng.key, (uint32_t)gd, (uint32_t)(gd >> 32), rng.t_lo, rng.t_hi};
+                            const uint4 x = rw.raw((lane < 8 ? 8u : 13u) + (uint32_t)lane);
+                            float nz[4], w[4];
+                            box_muller(x.x, x.y, nz[0], nz[1]);
+                            box_muller(x.z, x.w, nz[2], nz[3]);
+                            const bool is_normal = lane >= 4 && lane < 8;
+                            w[0] = is_normal ? nz[0] : u01(x.x); w[1] = is_normal ? nz[1] : u01(x.y);
+                            w[2] = is_normal ? nz[2] : u01(x.z); w[3] = is_normal ? nz[3] : u01(x.w);
+                            const bool mine = lane == d;
+#pragma unroll
+                            for (int j = 0; j < RS_ITEMS; ++j) {
+                                const bool wanted = j < 6 || (j < 8 && HAS(HLX_F_DOMAIN_RAND)) || (j >= 8 && HAS(HLX_F_VOLLEY) && j - 7 < VK);
+                                if (!wanted) continue;
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) {
+                                    const float v = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w[c]), j));
+                                    rd[j][c] = mine ? v : rd[j][c];
+                                }
+                            }
+                        }
+                    } else if (done) {
+#pragma unroll
+                        for (int j = 0; j < RS_ITEMS; ++j) {
+                            const bool wanted = j < 6 || (j < 8 && HAS(HLX_F_DOMAIN_RAND)) || (j >= 8 && HAS(HLX_F_VOLLEY) && j - 7 < VK);
+                            if (!wanted) continue;
+                            const uint4 x = rng.raw((j < 8 ? 8u : 13u) + (uint32_t)j + rsalt);
+                            if (j >= 4 && j < 8) { box_muller(x.x, x.y, rd[j][0], rd[j][1]); box_muller(x.z, x.w, rd[j][2], rd[j][3]); }
+                            else { rd[j][0] = u01(x.x); rd[j][1] = u01(x.y); rd[j][2] = u01(x.z); rd[j][3] = u01(x.w); }
+                        }
+                    }
+                }
                 if (done) {
                     if (MODE == 0) {
                         if (HOT(opt.terminal_obs)) {
@@ -724,11 +775,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     if (rbuf) {
 #pragma unroll
                         for (int k = 0; k < 10; ++k) u[k] = RN[k * N];
-                    } else {
-                        uint4 x0 = rng.raw(RS_RESET_U0 + rsalt), x1 = rng.raw(RS_RESET_U1 + rsalt), x2 = rng.raw(RS_RESET_U2 + rsalt);
-                        u[0] = u01(x0.x); u[1] = u01(x0.y); u[2] = u01(x0.z); u[3] = u01(x0.w);
-                        u[4] = u01(x1.x); u[5] = u01(x1.y); u[6] = u01(x1.z); u[7] = u01(x1.w);
-                        u[8] = u01(x2.x); u[9] = u01(x2.y);
+                    } else {   // items 0-2 = streams RS_RESET_U0..U2
+                        u[0] = rd[0][0]; u[1] = rd[0][1]; u[2] = rd[0][2]; u[3] = rd[0][3];
+                        u[4] = rd[1][0]; u[5] = rd[1][1]; u[6] = rd[1][2]; u[7] = rd[1][3];
+                        u[8] = rd[2][0]; u[9] = rd[2][1];
                     }
                     const V3 tp = v3(HOT(c.target[0]), HOT(c.target[1]), HOT(c.target[2]));
                     auto spawn_missile = [&](double u0, double u1, double u2, double u3, V3& mpos, V3& mvel) {
@@ -758,9 +808,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                                 if (rbuf) {
                                     const double* B = RN + (size_t)(32 + 4 * (m - 1)) * N;
                                     w0 = B[0]; w1 = B[N]; w2 = B[2 * N]; w3 = B[3 * N];
-                                } else {
-                                    const uint4 x = rng.raw(RS_RESET_V1 + (uint32_t)(m - 1) + rsalt);
-                                    w0 = u01(x.x); w1 = u01(x.y); w2 = u01(x.z); w3 = u01(x.w);
+                                } else {   // items 8-10 = streams RS_RESET_V1..
+                                    w0 = rd[7 + m][0]; w1 = rd[7 + m][1]; w2 = rd[7 + m][2]; w3 = rd[7 + m][3];
                                 }
                                 spawn_missile(w0, w1, w2, w3, vp[m], vv[m]);
                             }
@@ -810,10 +859,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                         if (rbuf) { zt = RN[20 * N]; zd = RN[21 * N]; zm = RN[22 * N]; zs = RN[23 * N]; }
                         else {
                             // draws 1..4 of the 13 (the others never reach the path): temperature, drag, mach, delay
-                            float z0_, f1, f2, f3, f4, z1_, z2_, z3_;
-                            rng.normals4(RS_DR0 + rsalt, z0_, f1, f2, f3);
-                            rng.normals4(RS_DR1 + rsalt, f4, z1_, z2_, z3_);
-                            zt = f1; zd = f2; zm = f3; zs = f4;
+                            zt = rd[6][1]; zd = rd[6][2]; zm = rd[6][3]; zs = rd[7][0];      // items 6, 7 = streams RS_DR0, RS_DR1
                         }
                         auto mult = [](double var, double z) { return fmin(fmax(1.0 + var * z, 0.1), 3.0); };
                         if (HAS(HLX_F_ATMOSPHERE)) T0 = T0 + k.dr_var[1] * zt;           // :258-261 (accumulates, float64)
@@ -843,12 +889,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                         const double* B = RN + 10 * N;
                         n_on = (float)B[0]; n_g = (float)B[1 * N]; n_gp = d3(B[2 * N], B[3 * N], B[4 * N]);
                         n_gv = d3(B[5 * N], B[6 * N], B[7 * N]); n_dl = B[8 * N];
-                    } else {
-                        const uint4 x = rng.raw(RS_RESET_OBS_U + rsalt);
-                        n_on = u01(x.x); n_g = u01(x.y); n_dl = (double)u01(x.z);
-                        V3 f; float w_;
-                        rng.normals4(RS_RESET_GPOS + rsalt, f.x, f.y, f.z, w_); n_gp = to_d3(f);
-                        rng.normals4(RS_RESET_GVEL + rsalt, f.x, f.y, f.z, w_); n_gv = to_d3(f);
+                    } else {   // items 3, 4, 5 = streams RS_RESET_OBS_U, RS_RESET_GPOS, RS_RESET_GVEL
+                        n_on = rd[3][0]; n_g = rd[3][1]; n_dl = (double)rd[3][2];
+                        n_gp = d3((double)rd[4][0], (double)rd[4][1], (double)rd[4][2]);
+                        n_gv = d3((double)rd[5][0], (double)rd[5][1], (double)rd[5][2]);
                     }
                 }
                 STAMP2(2);  // close-up: draws selected

@@ -10,9 +10,11 @@ This script disassembles the gfx950 code object inside the BUILT library (what s
 hlx_env_kernel instantiation, each VGPR that is a v_readlane source and never a v_writelane destination (those are the
 compiler's own SGPR-spill registers, which it saves in whole-wave mode): between the vector load that fills it and its
 last v_readlane it must not be written by ANYTHING (scratch reload, live-range-split copy back, another value borrowing
-the register), and no v_readlane may read a register that no vector load filled (a split COPY of a hot word, made under
-whatever EXEC mask was current).  The shipped kernels satisfy this with room to spare: the only v_readlane sources are
-the two load-filled hot words and the compiler's SGPR-spill registers.
+the register).  The hot words are the destinations of the kernel's single-dword vector loads (`global_load_dword`: the two
+loads of the parameter block; every other vector load of the kernel is wider).  Since round 2 the kernel also uses
+v_readlane on COMPUTED values (the wave-cooperative respawn draws, evaluated in wave-uniform control flow): such a source
+is accepted unless its last writer before the read is a plain copy of a hot word (`v_mov_b32 vX, vHOT`: a live-range
+split, made under whatever EXEC mask was current) or a scratch reload -- the two shapes the hazard can take.
 Usage: python -m hlynr_intercept_amd.hotcheck [libhlx.so | listing.s]; exit code 1 on a spill reload.
 hlynr_intercept_amd/build.py runs the same check after every build (`verify`)."""
 import collections
@@ -25,7 +27,27 @@ import tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-LLVM_BIN = os.environ.get("HLX_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+def _llvm_bin():
+    """Directory of llvm-objcopy / clang-offload-bundler / llvm-objdump: next to the hipcc that built the library
+    (<rocm>/bin/hipcc -> <rocm>/lib/llvm/bin), so a versioned ROCm install found through PATH works; HLX_LLVM_BIN overrides."""
+    import shutil
+    cands = [os.environ.get("HLX_LLVM_BIN")]
+    hipcc = shutil.which("hipcc")
+    if hipcc:
+        cands.append(os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "lib", "llvm", "bin"))
+    cands.append("/opt/rocm/lib/llvm/bin")
+    for c in cands:
+        if c and all(os.path.exists(os.path.join(c, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")):
+            return c
+    raise HotcheckToolsMissing("hotcheck tools not found (llvm-objcopy, clang-offload-bundler, llvm-objdump): looked in "
+                               + ", ".join(c for c in cands if c) + "; set HLX_LLVM_BIN")
+
+
+class HotcheckToolsMissing(RuntimeError):
+    """The disassembler tool chain is missing: the check could not RUN (distinct from a hot-word violation)."""
+
+
+LLVM_BIN = None
 
 
 def listing(path=None):
@@ -33,6 +55,8 @@ def listing(path=None):
     path = path or os.path.join(HERE, "libhlx.so")
     if path.endswith(".s"):
         return open(path).read()
+    global LLVM_BIN
+    LLVM_BIN = LLVM_BIN or _llvm_bin()
     tmp = tempfile.mkdtemp()
     fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "gfx950.co")
     subprocess.run([os.path.join(LLVM_BIN, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, path], check=True)
@@ -64,8 +88,8 @@ def check(text):
                     if lines[j].strip().startswith(".end_amdhsa_kernel") or (any_label.match(lines[j]) and "hlx_env_kernel" in lines[j])
                     or re.match(r"^[0-9a-f]+ <_Z", lines[j])), len(lines))
         readlane_src, writelane_dst = set(), set()
-        first_read, last_read = {}, {}
-        writes = collections.defaultdict(list)          # reg -> [(position, opcode)]
+        reads = collections.defaultdict(list)           # reg -> [positions of v_readlane]
+        writes = collections.defaultdict(list)          # reg -> [(position, opcode, source operands)]
         for pos, t in enumerate(x.strip() for x in lines[i + 1:end]):
             if not t or t.startswith((".", ";")):
                 continue
@@ -74,25 +98,34 @@ def check(text):
             if op == "v_readlane_b32":
                 for r in regs(parts[2]):
                     readlane_src.add(r)
-                    first_read.setdefault(r, pos)
-                    last_read[r] = pos
+                    reads[r].append(pos)
             if op == "v_writelane_b32":
                 writelane_dst.update(regs(parts[1]))
             if op.startswith(("v_", "global_load", "buffer_load", "scratch_load", "ds_read", "ds_bpermute", "flat_load")) and \
                     not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")) and len(parts) > 1:
                 for r in regs(parts[1]):
-                    writes[r].append((pos, op))
-        is_load = lambda op: op.startswith(("global_load", "buffer_load"))       # noqa: E731
+                    writes[r].append((pos, op, parts[2:]))
+        hot = {r for r, ws in writes.items() if any(op == "global_load_dword" for _, op, _ in ws)}
         for r in sorted(readlane_src - writelane_dst):
-            loads = [pos for pos, op in writes[r] if is_load(op) and pos < first_read[r]]
-            if not loads:
-                # a v_readlane of a register no load filled: a COPY of a hot word (live-range split) or a computed value.
-                # A copy made under a partial EXEC mask holds only the active lanes -- same hazard as a spill reload.
-                fail.append((name, f"v{r}", {"v_readlane of a register that no vector load wrote": 1}))
+            hot_loads = [pos for pos, op, _ in writes[r] if op == "global_load_dword" and pos < reads[r][0]]
+            if hot_loads:      # a hot word: nothing may write the register between its load and its last v_readlane
+                window = collections.Counter(op for pos, op, _ in writes[r] if max(hot_loads) < pos < reads[r][-1])
+                if window:     # scratch reload, or the register lent to other values while the hot word lives in a copy
+                    fail.append((name, f"v{r}", dict(window)))
                 continue
-            window = collections.Counter(op for pos, op in writes[r] if max(loads) < pos < last_read[r] and not is_load(op))
-            if window:   # scratch reload, or the register lent to other values while the hot word lives in a copy
-                fail.append((name, f"v{r}", dict(window)))
+            # a computed value read across lanes: its last writer before each read must not be a copy of a hot word
+            # (live-range split under a partial EXEC mask) nor a scratch reload
+            for rp in reads[r]:
+                prev = [(pos, op, src) for pos, op, src in writes[r] if pos < rp]
+                if not prev:
+                    fail.append((name, f"v{r}", {"v_readlane of a register nothing wrote": 1}))
+                    break
+                _, op, src = prev[-1]
+                if op.startswith("scratch_load") or (op.startswith("v_mov_b32") and any(x in hot for o in src for x in regs(o))):
+                    fail.append((name, f"v{r}", {"v_readlane of a " + ("scratch reload" if op.startswith("scratch") else "copy of a hot word"): 1}))
+                    break
+            else:
+                info.append((name, f"v{r}", len(reads[r])))
     return len(starts), fail, info
 
 

@@ -25,9 +25,16 @@ if os.environ.get("HLX_STAMP_LEVEL") == "2":
              "onboard ring etc", "obs: ground radar", "obs: datalink+fusion", "obs: fusion+Kalman", "obs: 26-D formulas",
              "obs: loop exit", "state stores", "compaction+tile store"]
 acc = []
+steady = os.environ.get("HLX_STAMP_STEADY", "1") == "1"
+print("kernel variant", env.kernel_variant, "baked", env.kernel_baked, "steady-state" if steady else "lock-step (right after reset)")
+tape = torch.rand((64, n, 6), generator=g, device=env.device) * 2 - 1
+if steady:      # desynchronise the episodes first (fused rollout), then time single-step launches as bench.py issues them
+    env.set_rollout_fused(64)
+    for _ in range(64):
+        env.rollout_torch(tape, 2)
+    env.set_rollout_fused(1)
 for t in range(60):
-    a = torch.rand((n, 6), generator=g, device=env.device) * 2 - 1
-    env.step_torch(a)
+    env.rollout_torch(tape[t:t + 1], 2)
     if t >= 20:
         buf = np.zeros(((n + 63) // 64, 16), np.uint64)
         assert lib.hlx_debug_read_stamps(env._h, buf.ctypes.data) == 0
@@ -36,6 +43,13 @@ for t in range(60):
 d = np.concatenate(acc)
 tot = d.sum(1)
 print(f"n={n} physics={physics}: median wave lifetime {np.median(tot):.0f} s_memtime ticks (100 MHz clock -> {np.median(tot)*10:.0f} ns)")
+q = np.percentile(tot, [10, 50, 90, 99, 100])
+print("  wave lifetime percentiles p10/p50/p90/p99/max:", " ".join(f"{x:.0f}" for x in q))
+slow = tot >= np.percentile(tot, 90)
+print(f"  slowest 10% of waves: median lifetime {np.median(tot[slow]):.0f}; per segment (median ticks, slow waves vs all):")
+for k, nm in enumerate(names[:d.shape[1]]):
+    print(f"    {nm:24s} {np.median(d[slow, k]):8.0f} vs {np.median(d[:, k]):8.0f}")
+# per launch: first start / last end over the waves (absolute stamps), i.e. how long the slowest wave keeps the launch open
 for k, nm in enumerate(names[:d.shape[1]]):
     print(f"  {nm:24s} median {np.median(d[:, k]):8.0f} ticks  share {100*np.median(d[:, k]/tot):5.1f}%")
 env.close()
