@@ -34,6 +34,9 @@ using namespace hlx;
 namespace {
 
 #define HAS(f) ((FL & (uint32_t)(f)) != 0u)
+// rare branches: laid out of line so that the hot path is one contiguous instruction stream (the step is ~2000 instructions
+// executed once per wave and launch: instruction fetch is cold, and every taken branch over a cold block breaks the prefetch)
+#define RARE(x) __builtin_expect(!!(x), 0)
 
 // Diagnostic build only (-DHLX_STAMPS): lane 0 of every wave records s_memtime at a few program points into
 // a.stamps[block][16].  No stamp executes in the product build, and no output is ever computed from one.
@@ -377,11 +380,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 los_basis(lu, h, v);
                 at = (lu * at.x + h * at.y) + v * at.z;                             // :1052-1056
             }
-            if (fuel <= 0.f) { at = at * 0.f; clamped = true; }                      // core.py:1080-1083
+            if (RARE(fuel <= 0.f)) { at = at * 0.f; clamped = true; }                      // core.py:1080-1083
             float am = snorm3(at);
-            if (am > 50.f) { at = at * HLX_DIVF(50.f, am); clamped = true; }                // core.py:1086-1090
+            if (RARE(am > 50.f)) { at = at * HLX_DIVF(50.f, am); clamped = true; }                // core.py:1086-1090
             float gm = snorm3(aw);
-            if (gm > 5.f) { aw = aw * HLX_DIVF(5.f, gm); clamped = true; }                  // core.py:1094-1098
+            if (RARE(gm > 5.f)) { aw = aw * HLX_DIVF(5.f, gm); clamped = true; }                  // core.py:1094-1098
 
             // Is the reference's wind a float64 array at this point?  Simple wind: float32 copy of
             // base_wind after reset, float64 from the first update on (environment.py:542,1127-1129).
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             }
             float fc = (divc(snorm3(thr), 1.0 / 500.0) * 0.1f) * HOT(c.dt);              // :883-884
             fuel = fuel - fc;
-            if (fuel <= 0.f) { fuel = 0.f; thr = v3(0.f, 0.f, 0.f); thrust_act = thr; } // :888-892
+            if (RARE(fuel <= 0.f)) { fuel = 0.f; thr = v3(0.f, 0.f, 0.f); thrust_act = thr; } // :888-892
             const V3 tacc = divc(thr, 1.0 / 500.0);                                 // :896
             float rho = 1.225f, sos = 343.f;
             if (HAS(HLX_F_ATMOSPHERE)) atmosphere(fmaxf(ipos.z, 0.f), (float)T0, rho, sos, &s_pow); // :899-906
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     w = v3((float)((double)w.x + (scale * z.x) * HOT(c.turb_lp)), (float)((double)w.y + (scale * z.y) * HOT(c.turb_lp)),
                            (float)((double)w.z + (scale * z.z) * HOT(c.turb_lp)));
                 }
-                if (gu < 0.001) {                                                   // :381-385
+                if (RARE(gu < 0.001)) {                                                   // :381-385
                     D3 gd; double e;
                     if (noise_buf) { gd = d3(SN[7 * N], SN[8 * N], SN[9 * N]); e = SN[10 * N]; }
                     else { V3 g; float ef; gust_draws(rng, g, ef); gd = to_d3(g); e = (double)ef; }
@@ -717,7 +720,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             for (int j = 0; j < RS_ITEMS; ++j) rd[j][0] = rd[j][1] = rd[j][2] = rd[j][3] = 0.f;
             if (pass == 1) {
                 const unsigned long long dmask = __ballot(done);
-                if (dmask == 0ull) break;
+                if (__builtin_expect(dmask == 0ull, 1)) break;
                 asm volatile("" : "+v"(rsalt));
                 const bool wide = (n - (int)blockIdx.x * 64) >= 64;      // every lane of the wave is live: all can serve
                 if (!rnoise_buf) {
@@ -910,13 +913,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     // only then -- about one env-step in 1e5 -- is the reference's operation order replayed.
                     const float cthr = HOT(cur.cos_half_beam);
                     float cb = clampf(fdot(fwd, rel) * __builtin_amdgcn_rcpf(range + 1e-6f), -1.f, 1.f);
-                    if (on_det && fabsf(cb - cthr) < 1e-5f) cb = clampf(sdot3(forward_vec_exact(q), rel / (range + 1e-6f)), -1.f, 1.f);
+                    if (RARE(on_det && fabsf(cb - cthr) < 1e-5f)) cb = clampf(sdot3(forward_vec_exact(q), rel / (range + 1e-6f)), -1.f, 1.f);
                     if (on_det && cb < cthr) { on_det = false; on_why = -2.f; }
                 }
                 STAMP2(5);  // close-up: beam angle (acosf)
                 if (on_det) {                                                       // :559-566
                     float aq = (HOT(c.radar_quality) * (1.0f - (range * HOT(c.inv_radar_range)) * 0.5f)) * HOT(cur.on_rel);
-                    if (fabsf(n_on - aq) < 2e-6f)   // Bernoulli draw within a few ulps of the probability: the reference's own division
+                    if (RARE(fabsf(n_on - aq) < 2e-6f))   // Bernoulli draw within a few ulps of the probability: the reference's own division
                         aq = (HOT(c.radar_quality) * (1.0f - HLX_DIVF(range, HOT(c.radar_range)) * 0.5f)) * HOT(cur.on_rel);
                     if (n_on > aq) { on_det = false; on_why = -3.f; }
                 }
@@ -944,19 +947,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     V3 g2m = mpos - gp;
                     // fast float32 first; the reference's own operations where a decision is within reach of the fast path's error
                     float grange = fnorm(g2m);
-                    if (fabsf(grange - HOT(c.g_max_range)) < 0.05f) grange = snorm3(g2m);
+                    if (RARE(fabsf(grange - HOT(c.g_max_range)) < 0.05f)) grange = snorm3(g2m);
                     g_det = !(grange > HOT(c.g_max_range));                              // :396
                     if (g_det && grange > 1e-6f) {                                  // :401-406  arcsin(s) against the elevation window:
                         // s against the float32 values at which the host's asinf crosses the two limits (hlx_host.inc)
                         float se = clampf(g2m.z * __builtin_amdgcn_rcpf(grange), -1.f, 1.f);
-                        if (fminf(fabsf(se - HOT(c.sin_min_elev)), fabsf(se - HOT(c.sin_max_elev))) < 4e-6f)
+                        if (RARE(fminf(fabsf(se - HOT(c.sin_min_elev)), fabsf(se - HOT(c.sin_max_elev))) < 4e-6f))
                             se = clampf(HLX_DIVF(g2m.z, snorm3(g2m)), -1.f, 1.f);
                         if (se < HOT(c.sin_min_elev) || se > HOT(c.sin_max_elev)) g_det = false;
                     }
                     if (mpos.z < 50.f) g_det = false;                               // :409
                     if (g_det) {                                                    // :413-418
                         float dpq = ((HOT(c.g_base_q) * (1.0f - (grange * HOT(c.inv_g_max_range)) * 0.4f)) * HOT(c.weather)) * HOT(cur.g_rel);
-                        if (fabsf(n_g - dpq) < 2e-6f)
+                        if (RARE(fabsf(n_g - dpq) < 2e-6f))
                             dpq = ((HOT(c.g_base_q) * (1.0f - HLX_DIVF(snorm3(g2m), HOT(c.g_max_range)) * 0.4f)) * HOT(c.weather)) * HOT(cur.g_rel);
                         if (n_g > dpq) g_det = false;
                         else {
@@ -1051,7 +1054,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     // lanes agree on the dtype -- the usual case -- executes one path of plain arithmetic.
                     const D3 zw = d3((double)ipos.x + z.x, (double)ipos.y + z.y, (double)ipos.z + z.z);            // :749
                     const V3 zf = to_v3(zw);                                        // the float32 measurement (when !m64)
-                    if (!kf_init) {                                                 // core.py:93-96
+                    if (RARE(!kf_init)) {                                           // core.py:93-96
                         kxp = to_d3(zf);
                         kxv = d3(0., 0., 0.);
                         kf_init = true;
