@@ -156,18 +156,27 @@ def config4(args, rank, local_rank, world, dist):
     t_roll = time.perf_counter() - t0
     # minibatch updates: forward + backward on a stand-in loss, ONE flat all-reduce each, optimiser step
     bucket = 0
-    t0 = time.perf_counter()
-    for k in range(args.minibatches):
+
+    def update(k, sec):
         o, a, r = kept[k % len(kept)]
-        with sections("update fwd+bwd"):
+        with sec("update fwd+bwd"):
             mean, value = policy(o)
             loss = ((mean - a) ** 2).mean() + 0.5 * ((value - r) ** 2).mean() + 1e-3 * policy.log_std.sum()
             opt.zero_grad(set_to_none=False)
             loss.backward()
-        with sections("gradient all-reduce"):
-            bucket = all_reduce_flat_grads(params, dist, world)
-        with sections("optimiser"):
+        with sec("gradient all-reduce"):
+            nbytes = all_reduce_flat_grads(params, dist, world)
+        with sec("optimiser"):
             opt.step()
+        return nbytes
+
+    update(0, Sections(torch))                   # warm: library kernel selection, allocator, communicator set-up
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(args.minibatches):
+        bucket = update(k, sections)
     torch.cuda.synchronize(dev)
     t_upd = time.perf_counter() - t0
     red = dev if args.backend == "nccl" else None

@@ -146,20 +146,16 @@ def load(build_if_missing: bool = True):
     if _lib is not None:
         return _lib
     path = _build.LIB
-    if build_if_missing and not os.path.exists(path) and not os.environ.get("HLX_LIBRARY"):
-        # Built in-tree by `__graft_entry__.build()` / `python -m hlynr_intercept_amd.build`.  If it is absent, one
-        # process per node builds it (local rank 0) and the others wait: N ranks compiling into the same file would race.
-        if os.environ.get("LOCAL_RANK", "0") == "0":
-            try:
-                _build.build(force=True)
-            except Exception as exc:  # pragma: no cover
+    if build_if_missing and not os.environ.get("HLX_LIBRARY"):
+        # Built in-tree by `__graft_entry__.build()` / `python -m hlynr_intercept_amd.build`.  A missing library, or one built
+        # from other sources than those in csrc/ (content hash), is (re)built here -- under a file lock, so that processes
+        # started together queue up instead of compiling into the same file (hlynr_intercept_amd/build.py).
+        try:
+            _build.build()
+        except Exception as exc:  # pragma: no cover
+            if not os.path.exists(path):
                 raise RuntimeError(f"libhlx.so is missing and could not be built: {exc}") from exc
-        else:  # pragma: no cover
-            import time
-            for _ in range(600):
-                if os.path.exists(path):
-                    break
-                time.sleep(0.5)
+            raise RuntimeError(f"libhlx.so is out of date with csrc/ and could not be rebuilt: {exc}") from exc
     if not os.path.exists(path):
         raise RuntimeError(f"HIP library not found at {path}: build it with `python -m hlynr_intercept_amd.build`")
     # One HIP runtime per process.  PyTorch-ROCm wheels carry their own libamdhip64 / libhsa-runtime64; libhlx.so names the

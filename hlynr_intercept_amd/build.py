@@ -68,35 +68,68 @@ def generate_baked(verbose: bool = False) -> str:
     return out
 
 
+def _src_hash() -> str:
+    """sha256 over the contents of every source the library is built from (mtimes do not survive a copy to another box)."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in sorted(DEPS + ["hlx_baked_gen.h"]):
+        path = os.path.join(CSRC, d)
+        if os.path.exists(path):
+            with open(path, "rb") as f:
+                h.update(d.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
+    """True when the library is missing or was built from different sources (content hash in libhlx.so.srchash)."""
     if os.environ.get("HLX_LIBRARY"):
         return False
     if not os.path.exists(LIB):
         return True
-    mt = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > mt for d in DEPS)
+    try:
+        with open(LIB + ".srchash") as f:
+            return f.read().strip() != _src_hash()
+    except OSError:
+        mt = os.path.getmtime(LIB)          # a library without its sidecar: fall back to modification times
+        return any(os.path.getmtime(os.path.join(CSRC, d)) > mt for d in DEPS)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Build (if needed) under an exclusive file lock: processes started together (pytest-xdist, several ranks without
+    LOCAL_RANK, notebooks) queue up instead of compiling into the same file; the compiler writes to a name unique to this
+    process and the result is renamed into place only after the hot-word check has passed."""
+    import fcntl
     if not force and not needs_build():
         return LIB
-    generate_baked(verbose)
-    tmp = LIB + ".unverified"
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-Wno-unused-value",
-           "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
-    # the constants of the step kernel are fetched across lanes (v_readlane): a register-allocator spill of those two
-    # VGPRs would silently corrupt them, so the code object is inspected before the library is put in place
-    from . import hotcheck
-    try:
-        hotcheck.verify(tmp)
-    except Exception:
-        os.replace(tmp, LIB + ".rejected")
-        raise
-    os.replace(tmp, LIB)
-    return LIB
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():      # somebody else built it while this process waited
+                return LIB
+            generate_baked(verbose)
+            tmp = f"{LIB}.{os.getpid()}.unverified"
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-Wno-unused-value",
+                   "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd, cwd=CSRC)
+            # the constants of the step kernel are fetched across lanes (v_readlane): a register-allocator spill of those two
+            # VGPRs would silently corrupt them, so the code object is inspected before the library is put in place
+            from . import hotcheck
+            try:
+                hotcheck.verify(tmp)
+            except hotcheck.HotcheckToolsMissing:
+                os.replace(tmp, LIB + ".unchecked")
+                raise
+            except Exception:
+                os.replace(tmp, LIB + ".rejected")
+                raise
+            os.replace(tmp, LIB)
+            with open(LIB + ".srchash", "w") as f:
+                f.write(_src_hash() + "\n")
+            return LIB
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def build_stamps(level: int = 1) -> str:

@@ -1014,7 +1014,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     fusion = clampf((float)(0.35 * HOT(c.radar_quality64)) + 0.50f * d_gq + 0.15f * agree, 0.f, 1.f);
                 }
                 if (pass == 0) {
-                    det_bits = (d_on_det ? 32u : 0u) | (d_g_det ? 64u : 0u);
+                    // bit 7: a delayed onboard sample exists (core.py:576-593): info['radar_quality'] is the configured quality then,
+                    // detected or not, and 0.0 only while the delay line is still filling
+                    det_bits = (d_on_det ? 32u : 0u) | (d_g_det ? 64u : 0u) | ((HOT(c.o_delay) == 0 || steps >= on_delay) ? 128u : 0u);
                     if (HAS(HLX_F_RADAR_DEBUG) && (slots & (1u << 20)) && HOT(opt.info.radar_debug)) {     // what info['radar_debug'] (core.py:650-683) cannot rebuild from positions
                         float* rd = HOT(opt.info.radar_debug) + i;
                         rd[0] = q.w; rd[N] = q.x; rd[2 * N] = q.y; rd[3 * N] = q.z;

@@ -108,8 +108,11 @@ class LazyInfos(Sequence):
             "missiles_intercepted": int(h["missiles"][i]) & 15, "missiles_remaining": int(h["missiles"][i]) >> 4,
             # environment.py:836-841 (read by train_hrl_pretrain.py:180-198, inference.py:535-560)
             "interceptor_pos": h["interceptor_pos"][:, i].copy(), "missile_pos": h["missile_pos"][:, i].copy(),
+            # fuel_used: the reference accumulates `total_fuel_used` step by step (environment.py:886); here it is 100 - fuel,
+            # equal up to float32 rounding and the overshoot of the step that empties the tank
             "steps": int(h["steps"][i]), "fuel_used": float(100.0 - h["fuel"][i]),
-            "radar_quality": float(h["radar_quality"]) if flags & 32 else 0.0,
+            # environment.py:840 <- core.py:536,584: the configured quality whenever a delayed onboard sample exists
+            "radar_quality": float(h["radar_quality"]) if flags & 128 else 0.0,
             # environment.py:848: per-missile closest approach in volley mode, [distance] otherwise
             "missile_min_distances": (h["missile_min_distances"][:h["volley"][1], i].tolist() if "missile_min_distances" in h
                                       else [float(h["distance"][i])]),

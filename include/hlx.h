@@ -121,7 +121,8 @@ typedef struct hlx_info_soa {
     float *fuel;              /* [N] info['fuel_remaining'] */
     uint8_t *flags;           /* [N] bit0 intercepted, bit1 missile_hit_target, bit2 proximity_fuze_triggered,
                                      bit3 clamped, bit4 crossed_threshold, bit5 onboard radar detected (delayed),
-                                     bit6 ground radar detected */
+                                     bit6 ground radar detected, bit7 a delayed onboard sample exists (the onboard delay
+                                     line has filled: info['radar_quality'] = the configured quality, else 0.0) */
     float *episode_return;    /* [N] written only for envs that finished this step (Monitor 'r') */
     int32_t *episode_length;  /* [N] written only for envs that finished this step (Monitor 'l') */
     uint8_t *missiles;        /* [N] low nibble info['missiles_intercepted'], high nibble info['missiles_remaining']

@@ -421,3 +421,23 @@ def test_baked_presets_are_selected_and_equal_the_runtime_constant_path(name, sc
         assert torch.equal(ra[4]["terminal_observation"], rb[4]["terminal_observation"])
     assert bytes(baked.get_state()) == bytes(plain.get_state())
     baked.close(); plain.close()
+
+
+def test_info_radar_quality_follows_the_onboard_delay_line():
+    """environment.py:840 <- core.py:536,584: info['radar_quality'] is the configured quality whenever a delayed onboard
+    sample exists (detected or not) and 0.0 only while the delay line is filling -- 3 samples with physics v2 (30 ms),
+    immediately without sensor delays (base physics)."""
+    n = 8
+    env = _env(n, physics="v2", over={"max_steps": 50})
+    env.reset()
+    seen = []
+    for t in range(8):
+        _, _, _, infos = env.step(np.zeros((n, 6), np.float32))
+        seen.append(infos[0]["radar_quality"])
+    assert seen[:2] == [0.0, 0.0] and all(q == env.rc.radar_quality for q in seen[2:]), seen   # step k holds k+1 samples; delay 3
+    env.close()
+    env = _env(n, physics="base")
+    env.reset()
+    _, _, _, infos = env.step(np.zeros((n, 6), np.float32))
+    assert infos[3]["radar_quality"] == env.rc.radar_quality
+    env.close()
