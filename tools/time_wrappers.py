@@ -7,20 +7,25 @@ from hlynr_intercept_amd.vec_env import HlynrVecEnv
 from hlynr_intercept_amd.wrappers import VecFrameStack, VecNormalize
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-K = 500
+K = 300
 
 
 def timed(stepper, acts):
-    for t in range(50):
+    """median / min over ten windows of K steps (single windows are at the mercy of one-off stalls: allocation, clock ramp)"""
+    for t in range(200):
         stepper(acts[t % len(acts)])
     torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for t in range(K):
-        stepper(acts[t % len(acts)])
-    b.record()
-    torch.cuda.synchronize()
-    return 1e3 * a.elapsed_time(b) / K
+    out = []
+    for w in range(10):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for t in range(K):
+            stepper(acts[t % len(acts)])
+        b.record()
+        torch.cuda.synchronize()
+        out.append(1e3 * a.elapsed_time(b) / K)
+    out.sort()
+    return out[len(out) // 2]
 
 
 env = HlynrVecEnv(scenario_config("medium", "base"), num_envs=n, seed=1)
