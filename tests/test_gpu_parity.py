@@ -343,7 +343,9 @@ def test_gpu_matches_oracle_free_running(scenario, physics, over, variant, late)
             sel = done & alive
             if sel.any():
                 assert np.max(np.abs(obs_h[sel] - out["obs"][sel])) <= OBS_ATOL
-    assert alive.mean() >= 0.995, f"{(~alive).sum()} of {n} envs diverged in their discrete history"
+    # detection decisions are taken with the reference's own arithmetic near their thresholds (hlx_kernels.hip): no environment
+    # may leave the oracle's discrete history -- round 1 tolerated 0.5 % of them
+    assert alive.all(), f"{(~alive).sum()} of {n} envs diverged in their discrete history"
     assert worst["obs"] <= OBS_ATOL, worst
     assert worst["distance"] <= RTOL, worst
     _check_reward_errors(np.concatenate(rew_errs), rc, (scenario, physics))
@@ -410,7 +412,7 @@ def test_gpu_matches_oracle_from_identical_state(scenario, physics, over, varian
         worst_obs = max(worst_obs, float(eo[ok].max(initial=0.0)))
         worst_dist = max(worst_dist, float(_rel(info["distance"].cpu().numpy(), out["distance"])[ok].max(initial=0.0)))
         rew_errs.append(_rel(rew.cpu().numpy(), out["reward"])[ok])
-    assert flag_mismatch <= max(1, n * T // 2000), flag_mismatch
+    assert flag_mismatch == 0, flag_mismatch
     assert worst_obs <= OBS_ATOL and worst_dist <= RTOL, (worst_obs, worst_dist)
     _check_reward_errors(np.concatenate(rew_errs), rc, (scenario, physics), resynced=True)
     env.close()
@@ -460,7 +462,7 @@ def test_full_size_batch_matches_oracle(physics, variant):
         if sel.any():
             worst["reset_obs"] = max(worst["reset_obs"], float(np.max(np.abs(obs_h[sel] - out["obs"][sel]))))
     assert n_done >= n, "every environment must have restarted inside the window"
-    assert alive.mean() >= 0.9995, f"{(~alive).sum()} of {n} envs diverged in their discrete history"
+    assert alive.all(), f"{(~alive).sum()} of {n} envs diverged in their discrete history"
     assert worst["obs"] <= OBS_ATOL and worst["reset_obs"] <= OBS_ATOL, worst
     assert worst["distance"] <= RTOL, worst
     _check_reward_errors(np.concatenate(rew_errs), rc, ("full size", physics))
