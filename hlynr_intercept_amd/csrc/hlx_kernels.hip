@@ -1109,7 +1109,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     const V3 frp = v3((float)(kxp.x - (double)ipos.x), (float)(kxp.y - (double)ipos.y), (float)(kxp.z - (double)ipos.z));
                     const V3 frv = to_v3(frv64);
                     const float rrange = fnorm_out(frp);
-                    const float closing = -fdiv(fdot(frp, frv), rrange + 1e-6f);    // :786
+                    float closing = -fdiv(fdot(frp, frv), rrange + 1e-6f);          // :786
+                    // Near closest approach the LOS is perpendicular to the relative velocity and the float32 dot product cancels
+                    // (600 m x 1500 m/s terms against a 5 m/s result): time-to-go obs[13] = 1 - range / closing / 100 then carries
+                    // 1e-4.  Where |cos| < 0.05 the reference's own arithmetic is replayed -- float64 once the filter state is.
+                    if (RARE(closing * closing < 2.5e-3f * fdot(frv, frv))) {
+                        if (kf_x64) {
+                            const D3 frp64 = d3(kxp.x - (double)ipos.x, kxp.y - (double)ipos.y, kxp.z - (double)ipos.z);
+                            closing = (float)(-ddot(frp64, frv64) / (sqrt(ddot(frp64, frp64)) + 1e-6));
+                        } else closing = -HLX_DIVF(sdot3(frp, frv), snorm3(frp) + 1e-6f);
+                    }
                     if (HAS(HLX_F_OBS_LOS)) {                                       // :791-868
                         row[0] = clampf(rrange * inv_mr, 0.f, 1.f);
                         row[1] = clampf(closing * inv_mv, -1.f, 1.f);

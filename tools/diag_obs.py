@@ -7,9 +7,11 @@ from hlynr_intercept_amd.config import resolve_config
 from hlynr_intercept_amd.scenarios import scenario_config
 from hlynr_intercept_amd.vec_env import HlynrVecEnv
 
-over = {"observation_mode": "los_frame", "proximity_fuze_enabled": True, "proximity_kill_radius": 60.0, "max_steps": 200}
-rc = resolve_config(scenario_config("medium", "v2", over))
-n, T = 4096, 260
+if len(sys.argv) > 1 and sys.argv[1] == "base":
+    over, phys, n, T = {}, "base", 8192, 2500
+else:
+    over, phys, n, T = {"observation_mode": "los_frame", "proximity_fuze_enabled": True, "proximity_kill_radius": 60.0, "max_steps": 200}, "v2", 4096, 260
+rc = resolve_config(scenario_config("medium", phys, over))
 env = HlynrVecEnv(resolved=rc, num_envs=n, seed=1234)
 ora = orc.OracleVec(rc, n)
 g = torch.Generator(device="cpu").manual_seed(7)
@@ -32,6 +34,6 @@ for t in range(T):
         if shown < 15:
             shown += 1
             so = np.frombuffer(ora.state, dtype=np.dtype(orc.OrcState))[i]
-            print(f"t={t} env={i} obs[{k}] gpu={og[i,k]!r} orc={oo[i,k]!r} | obs gpu {og[i,:9]} | kf_x={so['kf_x']} int_vel={so['int_vel']} steps={so['steps']} kf64={so['kf_x_is64']}")
+            print(f"t={t} env={i} obs[{k}] gpu={og[i,k]!r} orc={oo[i,k]!r} | obs gpu {og[i,:17]} | kf_x={so['kf_x']} int_pos={so['int_pos']} int_vel={so['int_vel']} steps={so['steps']} kf64={so['kf_x_is64']}")
 print("worst per index:", np.array2string(worst, precision=2))
 env.close()
