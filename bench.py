@@ -359,10 +359,25 @@ def main():
     achieved = bytes_per_launch / (kern_us * 1e-6) / 1e9 if launches else 0.0
     wall_us = 1e6 * elapsed / max(1, K)
 
+    # the same K steps with terminal observations requested (what hlx_step does for an SB3-style caller): finished
+    # environments are then observed twice -- terminal state, then the new episode -- and their waves take a second trip
+    # through the observation code
+    K2, W2 = min(K, 500), min(W, 64) or 1
+    env.set_rollout_terminal_obs(True)
+    run(W2)
+    sync_all()
+    env.profile(True)
+    ring, last_slot = run(K2)      # (the self-check below compares the outputs of this, the run's very last step)
+    sync_all()
+    tk_ms, tk_launches = env.profile_read()
+    env.profile(False)
+    env.set_rollout_terminal_obs(False)
+    two_pass_us = 1e3 * tk_ms / max(1, tk_launches)
+
     selfcheck = None
     if check is not None:     # the slabs and the oracle walk through the same D + W + K steps, then everything is compared
         check.reset()
-        for total in (D, W, K):
+        for total in (D, W, K, W2, K2):       # ... and the terminal-observation rollouts above
             for lo, hi in tape_schedule(total, tape_len):
                 for j in range(lo, hi):
                     check.step(tape[j])
@@ -435,7 +450,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "hlx_env_kernel<%s, step>" % variant,
                          "kernel_us": kern_us, "wall_us_per_step": wall_us, "frac_from_wall_clock": bytes_per_launch / (wall_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "launches_timed": launches},
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "launches_timed": launches,
+                         "with_terminal_observations": {"kernel_us": two_pass_us, "frac": bytes_per_launch / (two_pass_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                        "note": "same launches with hlx_set_rollout_terminal_obs: finished environments observed twice"}},
             "selfcheck": selfcheck,
             "cpu_baseline": cpu,
             "fused_rollout": fused,

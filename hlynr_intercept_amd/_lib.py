@@ -97,6 +97,7 @@ SYMBOLS = {
     "hlx_get_state": (C.c_int, [_P, _P]),
     "hlx_set_state": (C.c_int, [_P, _P]),
     "hlx_set_rollout_fused": (C.c_int, [_P, i32]),
+    "hlx_set_rollout_terminal_obs": (C.c_int, [_P, _P]),
     "hlx_set_seed": (C.c_int, [_P, u64]),
     "hlx_selftest_math": (C.c_int, [i32, _P, f32, _P, i64, _P]),
     "hlx_set_load_schedule": (C.c_int, [_P, i32]),

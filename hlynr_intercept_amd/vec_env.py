@@ -513,6 +513,10 @@ class HlynrVecEnv(_SB3VecEnv):
         self._torch.cuda.synchronize(self.device)
         _lib.check(self._lib.hlx_set_state(self._h, C.addressof(arr)))
 
+    def set_rollout_terminal_obs(self, enable: bool):
+        """rollout_torch (one launch per step) also fills `self.terminal_obs` for the environments that finish in a step."""
+        _lib.check(self._lib.hlx_set_rollout_terminal_obs(self._h, self.terminal_obs.data_ptr() if enable else None))
+
     def set_rollout_fused(self, steps_per_launch: int):
         """1 = one launch per step (default); k > 1 = rollout_torch keeps the state on-chip for k steps per launch."""
         _lib.check(self._lib.hlx_set_rollout_fused(self._h, int(steps_per_launch)))

@@ -218,6 +218,12 @@ int hlx_rollout(hlx_env *env, const float *actions, int32_t T, int32_t out_slots
  * observation/reward/flags/ring samples out).  Results are bit-identical either way (same Philox keys).
  * Ignored (falls back to 1) while hlx_set_noise buffers are installed. */
 int hlx_set_rollout_fused(hlx_env *env, int32_t steps_per_launch);
+/* hlx_rollout has no terminal-observation output; with a buffer installed here (device float [N][26], NULL removes it) its
+ * one-launch-per-step form writes, at every step, the terminal observation of the environments that finished in it
+ * (rows of the others are left untouched), exactly as hlx_step's `terminal_obs` does.  Costs the finished environments'
+ * waves a second trip through the observation code (single observation pass); ignored by the
+ * fused form. */
+int hlx_set_rollout_terminal_obs(hlx_env *env, float *terminal_obs);
 
 /* environment.py:269 set_training_step_count(): O(1) host-side; evaluates the curriculum
  * schedules (environment.py:223-234, :274-351) and the result rides along as kernel arguments. */

@@ -441,3 +441,32 @@ def test_info_radar_quality_follows_the_onboard_delay_line():
     _, _, _, infos = env.step(np.zeros((n, 6), np.float32))
     assert infos[3]["radar_quality"] == env.rc.radar_quality
     env.close()
+
+
+def test_single_observation_pass_equals_the_two_pass_form():
+    """Without a terminal-observation (or info) consumer the step kernel respawns finished lanes BEFORE its single
+    observation pass; with one it observes the terminal state first and the new episode in a second pass.  Same outputs,
+    same state, bit for bit -- and the terminal observations a rollout delivers through hlx_set_rollout_terminal_obs are
+    the ones hlx_step delivers."""
+    import torch
+    n, T = 900, 200
+    a_env, b_env, c_env = (_env(n, "v2dr", {"max_steps": 23}, seed=8) for _ in range(3))
+    g = torch.Generator(device=a_env.device).manual_seed(3)
+    tape = torch.rand((T, n, 6), generator=g, device=a_env.device) * 2 - 1
+    for e in (a_env, b_env, c_env):
+        e.reset_torch()
+    o, r, te, tr = (x.clone() for x in a_env.rollout_torch(tape, T))              # single pass
+    b_env.set_rollout_terminal_obs(True)
+    o2, r2, te2, tr2 = (x.clone() for x in b_env.rollout_torch(tape, T))          # two passes, rollout entry point
+    assert torch.equal(o, o2) and torch.equal(r, r2) and torch.equal(te, te2) and torch.equal(tr, tr2)
+    assert bytes(a_env.get_state()) == bytes(b_env.get_state())
+    n_done = 0
+    for t in range(T):                                                            # two passes, hlx_step
+        oc, rc_, tec, trc, info = c_env.step_torch(tape[t])
+        assert torch.equal(oc, o[t]) and torch.equal(rc_, r[t]) and torch.equal(tec, te[t]) and torch.equal(trc, tr[t]), t
+        n_done += int(((tec | trc) != 0).sum())
+    done_last = ((te[T - 1] | tr[T - 1]) != 0)
+    assert torch.equal(b_env.terminal_obs[done_last], c_env.terminal_obs[done_last])
+    assert n_done > 5 * n and bytes(a_env.get_state()) == bytes(c_env.get_state())
+    for e in (a_env, b_env, c_env):
+        e.close()
