@@ -241,6 +241,9 @@ def main():
                          "all-reduce (configs[3]), 5 = volley + HRL controller + LSTM state (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-selfcheck", action="store_true")
+    ap.add_argument("--no-terminal-obs-point", action="store_true",
+                    help="skip the second timing of the same launches with terminal observations requested (profiling runs: keeps "
+                         "the per-kernel averages of rocprofv3 about one form of the step only)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the barrier / max(time); gloo + --single-device rehearses the multi-rank "
                          "path on a one-GPU box")
@@ -362,17 +365,19 @@ def main():
     # the same K steps with terminal observations requested (what hlx_step does for an SB3-style caller): finished
     # environments are then observed twice -- terminal state, then the new episode -- and their waves take a second trip
     # through the observation code
-    K2, W2 = min(K, 500), min(W, 64) or 1
-    env.set_rollout_terminal_obs(True)
-    run(W2)
-    sync_all()
-    env.profile(True)
-    ring, last_slot = run(K2)      # (the self-check below compares the outputs of this, the run's very last step)
-    sync_all()
-    tk_ms, tk_launches = env.profile_read()
-    env.profile(False)
-    env.set_rollout_terminal_obs(False)
-    two_pass_us = 1e3 * tk_ms / max(1, tk_launches)
+    K2, W2 = (0, 0) if args.no_terminal_obs_point else (min(K, 500), min(W, 64) or 1)
+    two_pass_us = None
+    if K2:
+        env.set_rollout_terminal_obs(True)
+        run(W2)
+        sync_all()
+        env.profile(True)
+        ring, last_slot = run(K2)      # (the self-check below compares the outputs of this, the run's very last step)
+        sync_all()
+        tk_ms, tk_launches = env.profile_read()
+        env.profile(False)
+        env.set_rollout_terminal_obs(False)
+        two_pass_us = 1e3 * tk_ms / max(1, tk_launches)
 
     selfcheck = None
     if check is not None:     # the slabs and the oracle walk through the same D + W + K steps, then everything is compared
@@ -451,8 +456,9 @@ def main():
                          "kernel": "hlx_env_kernel<%s, step>" % variant,
                          "kernel_us": kern_us, "wall_us_per_step": wall_us, "frac_from_wall_clock": bytes_per_launch / (wall_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "launches_timed": launches,
-                         "with_terminal_observations": {"kernel_us": two_pass_us, "frac": bytes_per_launch / (two_pass_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                                        "note": "same launches with hlx_set_rollout_terminal_obs: finished environments observed twice"}},
+                         "with_terminal_observations": None if two_pass_us is None else {
+                             "kernel_us": two_pass_us, "frac": bytes_per_launch / (two_pass_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                             "note": "same launches with hlx_set_rollout_terminal_obs: finished environments observed twice"}},
             "selfcheck": selfcheck,
             "cpu_baseline": cpu,
             "fused_rollout": fused,
