@@ -16,6 +16,8 @@ of `--desync` steps (default 4096, ~30 ms; independent of --warmup): per-launch 
 Prints ONE JSON line on rank 0.  `value` = env-steps/s of the whole job (all ranks, max-over-ranks wall time around the
 K timed steps).  `roofline` = algorithmic bytes of one launch / mean launch duration, from HIP events recorded on the
 launch stream around the K back-to-back launches (dependent launches issued ahead of the GPU: the train has no gaps).
+`hlx_rollout` has no terminal-observation output (as in round 1), so its launches observe every environment once;
+`roofline.with_terminal_observations` times the same launches with that output requested.
 `selfcheck` = four 64-environment slabs of this rank's batch replayed from reset through every step of the run -- by
 the CPU oracle, fed the Philox draws the kernel consumed -- and compared with the timed rollout's own outputs and final
 state (non-zero exit status on a mismatch).  `cpu_baseline` = the CPU oracle timed on this host (rank 0, N = 1 only).
