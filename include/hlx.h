@@ -245,8 +245,9 @@ int hlx_fill_noise(hlx_env *env, double *step_noise, double *reset_noise, int32_
 int hlx_get_state(hlx_env *env, hlx_env_state *host_out);
 int hlx_set_state(hlx_env *env, const hlx_env_state *host_in);
 
-/* Kernel timing with HIP events recorded on the launch stream: one pair around every hlx_step launch,
- * one pair around the whole back-to-back launch train of an hlx_rollout call. */
+/* Kernel timing with HIP events recorded on the launch stream: one pair around every hlx_step launch; for an hlx_rollout
+ * call of T one-step launches, one pair from behind the first launch to behind the last (T - 1 launches back to back,
+ * without the host's launch latency ahead of the first); for the fused form one pair around the call. */
 int hlx_profile(hlx_env *env, int32_t enable);
 /* total elapsed ms between the event pairs and the number of step launches they covered
  * (synchronises, then clears) */
