@@ -45,8 +45,8 @@ tot = d.sum(1)
 print(f"n={n} physics={physics}: median wave lifetime {np.median(tot):.0f} s_memtime ticks (100 MHz clock -> {np.median(tot)*10:.0f} ns)")
 q = np.percentile(tot, [10, 50, 90, 99, 100])
 print("  wave lifetime percentiles p10/p50/p90/p99/max:", " ".join(f"{x:.0f}" for x in q))
-slow = tot >= np.percentile(tot, 90)
-print(f"  slowest 10% of waves: median lifetime {np.median(tot[slow]):.0f}; per segment (median ticks, slow waves vs all):")
+slow = tot >= np.percentile(tot, float(os.environ.get("HLX_STAMP_SLOW_PCT", "90")))
+print(f"  slowest waves (>= p{os.environ.get('HLX_STAMP_SLOW_PCT', '90')}): median lifetime {np.median(tot[slow]):.0f}; per segment (median ticks, slow waves vs all):")
 for k, nm in enumerate(names[:d.shape[1]]):
     print(f"    {nm:24s} {np.median(d[slow, k]):8.0f} vs {np.median(d[:, k]):8.0f}")
 # per launch: first start / last end over the waves (absolute stamps), i.e. how long the slowest wave keeps the launch open
