@@ -29,7 +29,7 @@ g = torch.Generator().manual_seed(5)
 sn, rn = env.fill_noise(for_reset=True)
 env.reset_torch()
 ora.reset(rn.cpu().numpy().T.copy())
-FIELDS = ["int_pos", "int_vel", "int_quat", "mis_pos", "mis_vel", "wind", "thrust_actual", "fuel", "prev_distance", "T0", "steps"]
+FIELDS = ["int_pos", "int_vel", "int_quat", "mis_pos", "mis_vel", "wind", "thrust_actual", "fuel", "prev_distance", "T0", "steps", "kf_x"]
 first = Counter()
 shown = 0
 nbad_r = 0
@@ -59,6 +59,6 @@ for t in range(T):
                 i = int(np.argmax(d)); shown += 1
                 print(f"t={t} env={i} field={f} gpu={x[i]!r} orc={y[i]!r}  pre int_pos={pre['int_pos'][i]} int_vel={pre['int_vel'][i]} "
                       f"mis_pos={pre['mis_pos'][i]} mis_vel={pre['mis_vel'][i]} wind={pre['wind'][i]} T0={pre['T0'][i]!r} "
-                      f"steps={pre['steps'][i]} thrust={pre['thrust_actual'][i]}")
+                      f"steps={pre['steps'][i]} kf_init={pre['kf_init'][i]} kf64={pre['kf_x_is64'][i]} kf_x_pre={pre['kf_x'][i]!r} g_len={pre['g_len'][i]}")
 print("env-steps", n * T, "reward>1e-5:", nbad_r, "fields differing (count of env-steps):", dict(first))
 env.close()

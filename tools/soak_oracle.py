@@ -16,6 +16,7 @@ from hlynr_intercept_amd.vec_env import HlynrVecEnv
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
+ONLY = os.environ.get("SOAK_ONLY")
 CASES = [
     ("medium", "base", {}), ("medium", "v2dr", {}), ("hard", "config", {}), ("easy", "config", {}), ("medium", "v2", {}),
     ("medium", "config", {"volley_mode": True, "volley_size": 3}),
@@ -25,7 +26,7 @@ CASES = [
     ("medium", "base", {"curriculum.precision_mode": True}),
     ("hard", "v2dr", {"max_steps": 300}),
 ]
-for scenario, physics, over in CASES:
+for scenario, physics, over in (CASES if not ONLY else [CASES[int(k)] for k in ONLY.split(",")]):
     rc = resolve_config(scenario_config(scenario, physics, over))
     env = HlynrVecEnv(resolved=rc, num_envs=n, seed=4321)
     ora = orc.OracleVec(rc, n)
@@ -54,7 +55,11 @@ for scenario, physics, over in CASES:
     st = np.frombuffer(env.get_state(), dtype=np.dtype(type(env.get_state()[0])))
     so = np.frombuffer(ora.state, dtype=np.dtype(type(ora.state[0])))
     state_bad = {f: int((st[f].astype(np.float64) != so[f].astype(np.float64)).any(axis=-1).sum() if st[f].ndim > 1 else (st[f] != so[f]).sum())
-                 for f in ("int_pos", "int_vel", "int_quat", "mis_pos", "mis_vel", "wind", "steps", "fuel")}
+                 for f in ("int_pos", "int_vel", "int_quat", "mis_pos", "mis_vel", "wind", "steps", "fuel", "kf_x")}
+    Po = so["kf_P"].reshape(n, 6, 6)
+    state_bad["kf_P"] = int((np.stack([Po[:, 0, 0], Po[:, 0, 3], Po[:, 3, 0], Po[:, 3, 3]], axis=1) != st["kf_P"].astype(np.float64)).any(axis=1).sum())
+    dk = np.abs(st["kf_x"] - so["kf_x"])
+    print(f"   kf_x max |diff|: position {dk[:, :3].max():.3e} m, velocity {dk[:, 3:].max():.3e} m/s (|v| min {np.abs(so['kf_x'][:, 3:]).max(axis=1).min():.3e})")
     k = int(np.argmax(worst_obs))
     print(f"{scenario}/{physics} {over} [{env.kernel_variant}{'+baked' if env.kernel_baked else ''}]: {n * T} env-steps, {n_done} episodes ended; "
           f"not bit-identical: {bad} state {state_bad}; worst obs entry [{k}] {worst_obs[k]:.2e} ({time.time() - t0:.0f} s)", flush=True)
