@@ -110,6 +110,16 @@ template <int BAKE, typename T, int OFF> DEV T hot_get(uint32_t w0, uint32_t w1)
         return v;
     } else return HotRd<T>::get(w0, w1, OFF);
 }
+// ... and the spawn / domain-randomisation constants a respawning lane needs (KCold): literals in the baked instantiations,
+// scalar loads from the parameter block otherwise (a cold s_load round trip is 1-2 k cycles for the lone wave of a SIMD,
+// on the path that keeps a launch open)
+template <int BAKE, int OFF> DEV double cold_get(const KParams* P) {
+    if constexpr (BAKE != 0) {
+        constexpr double v = BakedRd<double>::get(HLX_BAKED_COLD[BAKE - 1], OFF);
+        return v;
+    } else return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(&P->cold) + OFF);
+}
+#define COLD(path) (cold_get<BAKE, (int)offsetof(KCold, path)>(P))
 #define HOT(path) \
     (hot_get<BAKE, std::remove_cv_t<std::remove_reference_t<decltype(((const KHot*)nullptr)->path)>>, (int)offsetof(KHot, path)>(hotw0, hotw1))
 
@@ -731,7 +741,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             if (pass == 1 && __builtin_expect(dmask == 0ull, 1)) break;
             if (RARE(dmask != 0ull)) {
                 asm volatile("" : "+v"(rsalt));
-                const bool wide = (n - (int)blockIdx.x * 64) >= 64;      // every lane of the wave is live: all can serve
+                const bool wide = (n - (int)blockIdx.x * 64) >= RS_ITEMS;      // lanes 0..10, the ones that serve, are live
                 if (!rnoise_buf) {
                     if (wide) {
                         unsigned long long m = dmask;
@@ -760,13 +770,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                             }
                         }
                     } else if (done) {
-#pragma unroll
+                        // (a tail block with fewer than eleven live lanes: the lane draws for itself, one stream per trip of a
+                        // ROLLED loop -- this path runs for at most ten environments of a launch and must stay small: the
+                        // kernel's code is fetched cold at every launch, and every kilobyte of it is paid by the first wave
+                        // of each instruction cache to get there)
+#pragma unroll 1
                         for (int j = 0; j < RS_ITEMS; ++j) {
-                            const bool wanted = j < 6 || (j < 8 && HAS(HLX_F_DOMAIN_RAND)) || (j >= 8 && HAS(HLX_F_VOLLEY) && j - 7 < VK);
-                            if (!wanted) continue;
                             const uint4 x = rng.raw((j < 8 ? 8u : 13u) + (uint32_t)j + rsalt);
-                            if (j >= 4 && j < 8) { box_muller(x.x, x.y, rd[j][0], rd[j][1]); box_muller(x.z, x.w, rd[j][2], rd[j][3]); }
-                            else { rd[j][0] = u01(x.x); rd[j][1] = u01(x.y); rd[j][2] = u01(x.z); rd[j][3] = u01(x.w); }
+                            float w[4], nz[4];
+                            box_muller(x.x, x.y, nz[0], nz[1]);
+                            box_muller(x.z, x.w, nz[2], nz[3]);
+                            const bool is_normal = j >= 4 && j < 8;
+                            w[0] = is_normal ? nz[0] : u01(x.x); w[1] = is_normal ? nz[1] : u01(x.y);
+                            w[2] = is_normal ? nz[2] : u01(x.z); w[3] = is_normal ? nz[3] : u01(x.w);
+#pragma unroll
+                            for (int jj = 0; jj < RS_ITEMS; ++jj)
+                                if (jj == j) { rd[jj][0] = w[0]; rd[jj][1] = w[1]; rd[jj][2] = w[2]; rd[jj][3] = w[3]; }
                         }
                     }
                 }
@@ -782,7 +801,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                         if (HOT(opt.info.episode_length)) HOT(opt.info.episode_length)[i] = steps;
                     }
                     // ---------------- spawn (environment.py:375-567): float64 draws cast to float32
-                    const KCold& k = P->cold;
                     const bool rbuf = rnoise_buf;
                     double u[10];
                     if (rbuf) {
@@ -797,16 +815,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     auto spawn_missile = [&](double u0, double u1, double u2, double u3, V3& mpos, V3& mvel) {
                         if (HAS(HLX_F_SPHERICAL)) {                                 // :390-406
                             const double PI = 3.141592653589793;
-                            double radius = k.mis_radius[0] + k.mis_radius[1] * u0;
-                            double az = ((k.mis_az[0] + k.mis_az[1] * u1) * PI) / 180.0;
-                            double el = ((k.mis_el[0] + k.mis_el[1] * u2) * PI) / 180.0;
+                            double radius = COLD(mis_radius[0]) + COLD(mis_radius[1]) * u0;
+                            double az = ((COLD(mis_az[0]) + COLD(mis_az[1]) * u1) * PI) / 180.0;
+                            double el = ((COLD(mis_el[0]) + COLD(mis_el[1]) * u2) * PI) / 180.0;
                             mpos = v3((float)((double)tp.x + (radius * cos(el)) * cos(az)), (float)((double)tp.y + (radius * cos(el)) * sin(az)),
                                       (float)((double)tp.z + radius * sin(el)));
                         } else {                                                    // :409
-                            mpos = v3((float)(k.mis_lo[0] + k.mis_span[0] * u0), (float)(k.mis_lo[1] + k.mis_span[1] * u1),
-                                      (float)(k.mis_lo[2] + k.mis_span[2] * u2));
+                            mpos = v3((float)(COLD(mis_lo[0]) + COLD(mis_span[0]) * u0), (float)(COLD(mis_lo[1]) + COLD(mis_span[1]) * u1),
+                                      (float)(COLD(mis_lo[2]) + COLD(mis_span[2]) * u2));
                         }
-                        float speed = (float)(k.mis_speed[0] + k.mis_speed[1] * u3); // :415
+                        float speed = (float)(COLD(mis_speed[0]) + COLD(mis_speed[1]) * u3); // :415
                         V3 tt = tp - mpos;
                         float ttd = snorm3(tt);
                         mvel = (ttd > 1e-6f) ? (tt / ttd) * speed : v3(0.f, 0.f, 0.f); // :418-423
@@ -828,15 +846,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                             }
                         }
                     }
-                    ipos = v3((float)(k.int_lo[0] + k.int_span[0] * u[4]), (float)(k.int_lo[1] + k.int_span[1] * u[5]),
-                              (float)(k.int_lo[2] + k.int_span[2] * u[6]));         // :445
+                    ipos = v3((float)(COLD(int_lo[0]) + COLD(int_span[0]) * u[4]), (float)(COLD(int_lo[1]) + COLD(int_span[1]) * u[5]),
+                              (float)(COLD(int_lo[2]) + COLD(int_span[2]) * u[6]));         // :445
                     V3 rel0 = mpos - ipos;
                     float reld = snorm3(rel0);
                     if (HAS(HLX_F_TOWARD_MISSILE) && reld > 1e-6f)                  // :452-462
-                        ivel = (rel0 / reld) * (float)(k.int_speed[0] + k.int_speed[1] * u[7]);
+                        ivel = (rel0 / reld) * (float)(COLD(int_speed[0]) + COLD(int_speed[1]) * u[7]);
                     else                                                            // :467
-                        ivel = v3((float)(k.ivel_lo[0] + k.ivel_span[0] * u[7]), (float)(k.ivel_lo[1] + k.ivel_span[1] * u[8]),
-                                  (float)(k.ivel_lo[2] + k.ivel_span[2] * u[9]));
+                        ivel = v3((float)(COLD(ivel_lo[0]) + COLD(ivel_span[0]) * u[7]), (float)(COLD(ivel_lo[1]) + COLD(ivel_span[1]) * u[8]),
+                                  (float)(COLD(ivel_lo[2]) + COLD(ivel_span[2]) * u[9]));
                     V3 orel = rel0;
                     float oreld = reld;
                     if (HAS(HLX_F_VOLLEY)) {   // per-missile minimum distances (:469-473); point at the CLOSEST missile (:476-487)
@@ -858,9 +876,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                         double ax = -(double)fd.y, ay = (double)fd.x;
                         double axl = sqrt(ax * ax + ay * ay);
                         if (axl > 1e-6) {
-                            double half = acos(fmin(fmax((double)fd.z, -1.0), 1.0)) / 2.0;
-                            double sh = sin(half);
-                            q = Quat{(float)cos(half), (float)((ax / axl) * sh), (float)((ay / axl) * sh), 0.f};
+                            // cos(acos(c) / 2) = sqrt((1 + c) / 2), sin(acos(c) / 2) = sqrt((1 - c) / 2): two float64 square roots instead
+                            // of acos + sin + cos -- several thousand cycles on the respawn path, i.e. on the waves that keep a launch
+                            // open (8.80 against 9.37 us per launch, A/B).  Equal to the reference's float64 values to a few
+                            // ulp(float64): the float32 quaternion can differ in its last bit with probability ~1e-8 per component.
+                            const double cz = fmin(fmax((double)fd.z, -1.0), 1.0);
+                            const double chalf = sqrt((1.0 + cz) * 0.5), sh = sqrt((1.0 - cz) * 0.5);
+                            q = Quat{(float)chalf, (float)((ax / axl) * sh), (float)((ay / axl) * sh), 0.f};
                         } else if (!(fd.z > 0.f)) q = Quat{0.f, 1.f, 0.f, 0.f};
                     }
                     on_delay = HOT(c.o_delay);                                           // constructor value (core.py:292-293)
@@ -875,14 +897,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                             zt = rd[6][1]; zd = rd[6][2]; zm = rd[6][3]; zs = rd[7][0];      // items 6, 7 = streams RS_DR0, RS_DR1
                         }
                         auto mult = [](double var, double z) { return fmin(fmax(1.0 + var * z, 0.1), 3.0); };
-                        if (HAS(HLX_F_ATMOSPHERE)) T0 = T0 + k.dr_var[1] * zt;           // :258-261 (accumulates, float64)
+                        if (HAS(HLX_F_ATMOSPHERE)) T0 = T0 + COLD(dr_var[1]) * zt;           // :258-261 (accumulates, float64)
                         if (HAS(HLX_F_MACH_DRAG)) {                                 // :270-280
-                            const double cd64 = 0.3 * mult(k.dr_var[2], zd);
+                            const double cd64 = 0.3 * mult(COLD(dr_var[2]), zd);
                             dp.base_cd = (float)cd64; dp.cd_super = (float)(cd64 * HOT(c.super_mult));
-                            dp.peak_m1 = (float)(3.0 * mult(k.dr_var[3], zm) - 1.0);
+                            dp.peak_m1 = (float)(3.0 * mult(COLD(dr_var[3]), zm) - 1.0);
                         }
                         if (HOT(c.o_delay) > 0)                                          // :289-297
-                            on_delay = min(10, max(1, (int)(3.0 * mult(k.dr_var[4], zs))));
+                            on_delay = min(10, max(1, (int)(3.0 * mult(COLD(dr_var[4]), zs))));
                     }
                     steps = 0; ep_return = 0.f;                                     // :565-566
                     kf_init = false; kf_x64 = false;                                // core.py:65-69
