@@ -793,9 +793,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     fresh = true;
                     if (MODE == 0 && pass == 1) {
                         if (HOT(opt.terminal_obs)) {
-                            float* to = HOT(opt.terminal_obs) + (size_t)i * HLX_OBS_DIM;
+                            // the lane's row of the LDS tile (pass 0's observation of the terminal state) -> terminal_obs[i]: all
+                            // thirteen 8-byte LDS reads first, then thirteen GLOBAL stores (through a generic pointer the
+                            // compiler must assume the store may hit LDS and serialises read / wait / store 26 times)
+                            typedef float f2v_ __attribute__((ext_vector_type(2)));
+                            typedef __attribute__((address_space(1))) f2v_ gf2v_;
+                            gf2v_* to = (gf2v_*)(HOT(opt.terminal_obs) + (size_t)i * HLX_OBS_DIM);
+                            const f2v_* r2 = reinterpret_cast<const f2v_*>(row);
+                            f2v_ tv[HLX_OBS_DIM / 2];
 #pragma unroll
-                            for (int k = 0; k < HLX_OBS_DIM; ++k) to[k] = row[k];
+                            for (int k = 0; k < HLX_OBS_DIM / 2; ++k) tv[k] = r2[k];
+#pragma unroll
+                            for (int k = 0; k < HLX_OBS_DIM / 2; ++k) to[k] = tv[k];
                         }
                         if (HOT(opt.info.episode_return)) HOT(opt.info.episode_return)[i] = ep_return;
                         if (HOT(opt.info.episode_length)) HOT(opt.info.episode_length)[i] = steps;
