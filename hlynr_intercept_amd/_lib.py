@@ -135,6 +135,7 @@ SYMBOLS = {
 }
 
 _lib = None
+_load_error = None
 
 
 class HlxError(RuntimeError):
@@ -143,9 +144,20 @@ class HlxError(RuntimeError):
 
 def load(build_if_missing: bool = True):
     """Load libhlx.so (building it in-tree with hipcc if absent).  Fails loudly; never falls back."""
-    global _lib
+    global _lib, _load_error
     if _lib is not None:
         return _lib
+    if _load_error is not None:      # one failed (re)build per process is enough: every later caller gets the same error at once
+        raise _load_error
+    try:
+        return _load(build_if_missing)
+    except Exception as exc:
+        _load_error = exc
+        raise
+
+
+def _load(build_if_missing: bool):
+    global _lib
     path = _build.LIB
     if build_if_missing and not os.environ.get("HLX_LIBRARY"):
         # Built in-tree by `__graft_entry__.build()` / `python -m hlynr_intercept_amd.build`.  A missing library, or one built

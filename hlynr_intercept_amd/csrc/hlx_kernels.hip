@@ -34,6 +34,17 @@ using namespace hlx;
 namespace {
 
 #define HAS(f) ((FL & (uint32_t)(f)) != 0u)
+// LDS hand-over between the lanes of ONE wave (every workgroup of this kernel is a single wavefront): the LDS pipeline
+// executes a wave's DS instructions in issue order, so a later ds_read already sees the earlier ds_writes of other lanes;
+// all that is needed is that the compiler keeps the program order.  __syncthreads() would add `s_waitcnt vmcnt(0)` -- on
+// this part that also waits for every outstanding STORE, and behind the state stores it stalled the wave for their
+// write-through acknowledgements before the observation tile could leave.
+#define WAVE_LDS_SYNC()                                           \
+    do {                                                          \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+        __builtin_amdgcn_wave_barrier();                          \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+    } while (0)
 // rare branches: laid out of line so that the hot path is one contiguous instruction stream (the step is ~2000 instructions
 // executed once per wave and launch: instruction fetch is cold, and every taken branch over a cold block breaks the prefetch)
 #define RARE(x) __builtin_expect(!!(x), 0)
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         if (!PERSIST) asm volatile("" : "+v"(hotw0), "+v"(hotw1));
         if (need_pow && kk == 0) {
             reinterpret_cast<unsigned long long*>(&s_pow)[lane] = pow_word;
-            __syncthreads();   // one wave per workgroup: orders the LDS writes before the per-lane lookups below
+            WAVE_LDS_SYNC();   // one wave per workgroup: orders the LDS writes before the per-lane lookups below
         }
         done_idx_out = HOT(opt.done_idx);
         if (live) {   // ============================== per-environment work, live lanes only ==============================
@@ -658,6 +669,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         }
 
         STAMP(7);   // reward
+        // Kalman / ring registers become visible here (their loads were issued last, right behind the Philox block).  BEFORE
+        // the scalar output stores below: vmcnt counts loads and stores in one in-order queue on this part, so a wait for
+        // these loads placed behind the stores also waits for the stores' acknowledgements -- a store latency stall that a
+        // lone wave eats in full (the late loads themselves landed thousands of cycles ago).
+        PIN4(g_kfp); PIN2(g_kf0); PIN2(g_kf1); PIN2(g_kf2); PIN2(gr0); PIN4(gr1); PIN4(gr2);
         // ---------------------------------------------------------------------- early scalar outputs
         // The step's scalar outputs go out now, while ~5k cycles of observation math follow.  (Storing the
         // integrator's state groups here as well was measured: +0.5 us/step at 65 536 envs -- the stores
@@ -695,8 +711,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             }
             }
         }
-        // Kalman / ring registers become visible here (their loads were issued last, at kernel entry)
-        PIN4(g_kfp); PIN2(g_kf0); PIN2(g_kf1); PIN2(g_kf2); PIN2(gr0); PIN4(gr1); PIN4(gr2);
 #undef PIN4
 #undef PIN2
         D3 kxp = d3(g_kf0.x, g_kf0.y, g_kf1.x), kxv = d3(g_kf1.y, g_kf2.x, g_kf2.y);
@@ -1325,7 +1339,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
 
     // -------------------------------------------------------------------------- observation tile -> [N][26]
     if (obs_out) {
-        __syncthreads();
+        WAVE_LDS_SYNC();
         const int rows = min(64, n - blockIdx.x * 64);
         float* dst = obs_out + (size_t)blockIdx.x * 64 * HLX_OBS_DIM;
         if (MODE == 0) {
@@ -1357,7 +1371,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         if (obs_out0) obs_out = obs_out0 + (size_t)oslot * n * HLX_OBS_DIM;
         reward_out = reward_out0 + (size_t)oslot * n; term_out = term_out0 + (size_t)oslot * n; trunc_out = trunc_out0 + (size_t)oslot * n;
         done = false;
-        __syncthreads();   // the tile is rewritten by the next step
+        WAVE_LDS_SYNC();   // the tile is rewritten by the next step
     }
     }   // step loop
     if (PERSIST && blockIdx.x == 0 && lane == 0) { P->done_cnt[0] = 0; P->done_cnt[1] = 0; }   // nothing was listed in this launch

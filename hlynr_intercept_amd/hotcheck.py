@@ -9,12 +9,13 @@ instantiation of the generic variant, at 256 VGPRs with 440 B of scratch, lost `
 This script disassembles the gfx950 code object inside the BUILT library (what ships) and checks, for every
 hlx_env_kernel instantiation, each VGPR that is a v_readlane source and never a v_writelane destination (those are the
 compiler's own SGPR-spill registers, which it saves in whole-wave mode): between the vector load that fills it and its
-last v_readlane it must not be written by ANYTHING (scratch reload, live-range-split copy back, another value borrowing
-the register).  The hot words are the destinations of the kernel's single-dword vector loads (`global_load_dword`: the two
-loads of the parameter block; every other vector load of the kernel is wider).  Since round 2 the kernel also uses
-v_readlane on COMPUTED values (the wave-cooperative respawn draws, evaluated in wave-uniform control flow): such a source
-is accepted unless its last writer before the read is a plain copy of a hot word (`v_mov_b32 vX, vHOT`: a live-range
-split, made under whatever EXEC mask was current) or a scratch reload -- the two shapes the hazard can take.
+every v_readlane is classified by what its source register holds AT THAT POINT -- the last instruction that wrote it:
+the parameter-block load itself (`global_load_dword`: the kernel's only single-dword vector loads) = a hot word with all
+64 lanes valid; an ordinary computation = a computed value read across lanes (since round 2: the wave-cooperative respawn
+draws, evaluated in wave-uniform control flow); a plain copy whose chain leads back to a hot word (`v_mov_b32 vX, vHOT`:
+a live-range split, possibly copied back later), a scratch reload or an AGPR read-back = the hazard, made under whatever
+EXEC mask was current.  Registers are recycled (a baked instantiation may never read one of its hot words and reuse the
+register for something else), so the classification is per read, not per register.
 Usage: python -m hlynr_intercept_amd.hotcheck [libhlx.so | listing.s]; exit code 1 on a spill reload.
 hlynr_intercept_amd/build.py runs the same check after every build (`verify`)."""
 import collections
@@ -105,27 +106,43 @@ def check(text):
                     not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")) and len(parts) > 1:
                 for r in regs(parts[1]):
                     writes[r].append((pos, op, parts[2:]))
-        hot = {r for r, ws in writes.items() if any(op == "global_load_dword" for _, op, _ in ws)}
+        def last_write(r, pos):
+            prev = [w for w in writes.get(r, ()) if w[0] < pos]
+            return prev[-1] if prev else None
+
+        def origin(r, pos, depth=0):
+            """what the value in register r at position pos IS: 'hot' (filled by the parameter-block load), 'copy-of-hot',
+            'reload' (scratch / AGPR spill space), 'nothing', or 'computed'"""
+            w = last_write(r, pos)
+            if w is None:
+                return "nothing"
+            wpos, op, src = w
+            if op == "global_load_dword":
+                return "hot"
+            if op.startswith("scratch_load") or op.startswith("v_accvgpr_read"):
+                return "reload"
+            if op.startswith("v_mov_b32") and depth < 8:
+                for o in src[:1]:
+                    for x in regs(o):
+                        inner = origin(x, wpos, depth + 1)
+                        if inner in ("hot", "copy-of-hot"):
+                            return "copy-of-hot"
+                        if inner == "reload":
+                            return "reload"
+            return "computed"
+
+        # Every v_readlane is classified by what its source register holds AT THAT POINT (registers are recycled: the
+        # register of a hot word that a baked instantiation never reads may later carry a computed value):
+        #   hot        -- still the value the parameter-block load put there: all 64 lanes valid, fine;
+        #   computed   -- an ordinary value (the wave-cooperative respawn draws, evaluated in wave-uniform control flow);
+        #   copy / reload of a hot word -- made under whatever EXEC mask was current: the hazard this check exists for.
         for r in sorted(readlane_src - writelane_dst):
-            hot_loads = [pos for pos, op, _ in writes[r] if op == "global_load_dword" and pos < reads[r][0]]
-            if hot_loads:      # a hot word: nothing may write the register between its load and its last v_readlane
-                window = collections.Counter(op for pos, op, _ in writes[r] if max(hot_loads) < pos < reads[r][-1])
-                if window:     # scratch reload, or the register lent to other values while the hot word lives in a copy
-                    fail.append((name, f"v{r}", dict(window)))
-                continue
-            # a computed value read across lanes: its last writer before each read must not be a copy of a hot word
-            # (live-range split under a partial EXEC mask) nor a scratch reload
-            for rp in reads[r]:
-                prev = [(pos, op, src) for pos, op, src in writes[r] if pos < rp]
-                if not prev:
-                    fail.append((name, f"v{r}", {"v_readlane of a register nothing wrote": 1}))
-                    break
-                _, op, src = prev[-1]
-                if op.startswith("scratch_load") or (op.startswith("v_mov_b32") and any(x in hot for o in src for x in regs(o))):
-                    fail.append((name, f"v{r}", {"v_readlane of a " + ("scratch reload" if op.startswith("scratch") else "copy of a hot word"): 1}))
-                    break
+            kinds = collections.Counter(origin(r, rp) for rp in reads[r])
+            bad = {k: v for k, v in kinds.items() if k in ("copy-of-hot", "reload", "nothing")}
+            if bad:
+                fail.append((name, f"v{r}", {"v_readlane of a " + k: v for k, v in bad.items()}))
             else:
-                info.append((name, f"v{r}", len(reads[r])))
+                info.append((name, f"v{r}", dict(kinds)))
     return len(starts), fail, info
 
 

@@ -20,14 +20,24 @@ _ZN12_GLOBAL__N_114hlx_env_kernelILj1ELi0ELb0EEEvv:
 
 def test_checker_flags_a_spilled_hot_word_and_ignores_sgpr_spill_registers():
     n, fail, _ = hotcheck.check(SPILLED)
-    assert n == 1 and [(r, ops) for _, r, ops in fail] == [("v5", {"v_mov_b32_e32": 1, "scratch_load_dword": 1})]
+    assert n == 1 and [(r, ops) for _, r, ops in fail] == [("v5", {"v_readlane of a reload": 1})]
     clean = SPILLED.replace("\tscratch_load_dword v5, off, off offset:4\n", "").replace("\tv_mov_b32_e32 v5, 0\n", "")
     n, fail, _ = hotcheck.check(clean)
     assert n == 1 and not fail
     # reading a COPY of the hot word is refused too (the copy holds only the lanes that were active when it was made)
     copied = clean.replace("\tv_readlane_b32 s1, v5, 7\n", "\tv_mov_b32_e32 v6, v5\n\tv_readlane_b32 s1, v6, 7\n")
     n, fail, _ = hotcheck.check(copied)
-    assert [r for _, r, _ in fail] == ["v6"]
+    assert [(r, ops) for _, r, ops in fail] == [("v6", {"v_readlane of a copy-of-hot": 1})]
+    # ... also when the hot word is parked in a copy, its register lent to something else, and the copy moved back
+    parked = clean.replace("\tv_readlane_b32 s1, v5, 7\n",
+                           "\tv_mov_b32_e32 v6, v5\n\tv_add_f32_e32 v5, v2, v3\n\tv_mov_b32_e32 v5, v6\n\tv_readlane_b32 s1, v5, 7\n")
+    n, fail, _ = hotcheck.check(parked)
+    assert [(r, ops) for _, r, ops in fail] == [("v5", {"v_readlane of a copy-of-hot": 1})]
+    # a register that once held a hot word and now holds a computed value may be read across lanes (registers are recycled;
+    # the wave-cooperative respawn draws are such values)
+    recycled = clean.replace("\tv_readlane_b32 s1, v5, 7\n", "\tv_mul_f32_e32 v5, v2, v3\n\tv_readlane_b32 s1, v5, 7\n")
+    n, fail, info = hotcheck.check(recycled)
+    assert not fail and ("v5", {"hot": 1, "computed": 1}) in [(r, k) for _, r, k in info]
 
 
 def test_built_library_keeps_hot_words_in_registers():
