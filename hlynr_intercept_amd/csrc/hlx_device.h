@@ -356,9 +356,10 @@ DEV D3 mach_drag_force64(D3 v, float rho, float sos, double area, const DragPara
     return D3{(-v.x / vm) * a, (-v.y / vm) * a, (-v.z / vm) * a};
 }
 // environment.py:927-930 / 1111-1113 nan_to_num(nan=0, +-inf=+-lim), applied when any component is non-finite
+DEV bool nan_hit(D3 a) {   // |x| + |y| + |z| is finite exactly when all three are (no cancellation between non-negative terms)
+    return !isfinite((fabs(a.x) + fabs(a.y)) + fabs(a.z));
+}
 DEV D3 nan_guard(D3 a, double lim) {
-    bool ok = isfinite(a.x) && isfinite(a.y) && isfinite(a.z);
-    if (__builtin_expect(ok, 1)) return a;
     auto fix = [lim](double x) { return isnan(x) ? 0.0 : (isinf(x) ? (x > 0. ? lim : -lim) : x); };
     return D3{fix(a.x), fix(a.y), fix(a.z)};
 }

@@ -52,11 +52,16 @@ namespace {
 // Diagnostic build only (-DHLX_STAMPS): lane 0 of every wave records s_memtime at a few program points into
 // a.stamps[block][16].  No stamp executes in the product build, and no output is ever computed from one.
 #ifdef HLX_STAMPS
+#ifdef HLX_STAMP_REALTIME      // one 100 MHz counter for the whole chip (s_memtime counts per CU, unsynchronised): launch timelines
+#define STAMP_CLOCK "s_memrealtime"
+#else
+#define STAMP_CLOCK "s_memtime"
+#endif
 #define STAMP_RAW(k)                                                                                       \
     do {                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                             \
         unsigned long long t_;                                                                         \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                      \
+        asm volatile(STAMP_CLOCK " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                      \
         if (lane == 0) stamp_base[(k)] = t_;                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                             \
     } while (0)
@@ -427,7 +432,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             float rho = 1.225f, sos = 343.f;
             if (HAS(HLX_F_ATMOSPHERE)) atmosphere(fmaxf(ipos.z, 0.f), (float)T0, rho, sos, &s_pow); // :899-906
             const float GRAV = -9.81f;
-            if (w64) {                                                              // float64 air-relative velocity
+            // Common case first and unconditionally, the rare one as an override behind RARE(): an if/else keeps both bodies
+            // in line, and the lone wave of a SIMD pays an instruction-buffer refill for every branch TAKEN -- here the jump
+            // over the body that no lane needs.  (The float32 form serves the first step of an episode only.)
+            V3 ivel_n = ivel;
+            if (simple_wind) {                                                      // float64 air-relative velocity (never with the enhanced wind model)
                 D3 va = to_d3(ivel) - wind;                                         // :910
                 D3 dacc;
                 if (HAS(HLX_F_MACH_DRAG) && dnorm(va) > 1e-6) dacc = mach_drag_force64(va, rho, sos, 1.0, dp) * (1.0 / 500.0);
@@ -439,10 +448,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     dacc = d3((c2 * va.x) * (1.0 / 500.0), (c2 * va.y) * (1.0 / 500.0), (c2 * va.z) * (1.0 / 500.0));
                 }
                 D3 acc = d3((double)tacc.x + dacc.x, (double)tacc.y + dacc.y, ((double)tacc.z + dacc.z) + (double)GRAV); // :924
-                if (HAS(HLX_F_VALIDATION)) acc = nan_guard(acc, 50.0);
-                ivel = v3((float)((double)ivel.x + acc.x * HOT(c.dt64)), (float)((double)ivel.y + acc.y * HOT(c.dt64)),
-                          (float)((double)ivel.z + acc.z * HOT(c.dt64)));                // :933
-            } else {
+                ivel_n = v3((float)((double)ivel.x + acc.x * HOT(c.dt64)), (float)((double)ivel.y + acc.y * HOT(c.dt64)),
+                            (float)((double)ivel.z + acc.z * HOT(c.dt64)));              // :933
+                if (HAS(HLX_F_VALIDATION) && RARE(nan_hit(acc))) {                  // :927-930, out of line: repair, then the same update
+                    acc = nan_guard(acc, 50.0);
+                    ivel_n = v3((float)((double)ivel.x + acc.x * HOT(c.dt64)), (float)((double)ivel.y + acc.y * HOT(c.dt64)),
+                                (float)((double)ivel.z + acc.z * HOT(c.dt64)));
+                    asm volatile("" : "+v"(ivel_n.x), "+v"(ivel_n.y), "+v"(ivel_n.z));   // (keeps the optimiser from merging the two updates back into one behind an if/else on `acc`)
+                }
+            }
+            if (RARE(!w64)) {
                 V3 va = ivel - to_v3(wind);
                 V3 dacc;
                 if (HAS(HLX_F_MACH_DRAG) && snorm3(va) > 1e-6f) dacc = divc(mach_drag_force(va, rho, sos, 1.0f, dp), 1.0 / 500.0);
@@ -452,9 +467,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     dacc = divc(va * c2, 1.0 / 500.0);
                 }
                 V3 acc = v3(tacc.x + dacc.x, tacc.y + dacc.y, (tacc.z + dacc.z) + GRAV);
-                if (HAS(HLX_F_VALIDATION)) acc = to_v3(nan_guard(to_d3(acc), 50.0));
-                ivel = ivel + acc * HOT(c.dt);
+                if (HAS(HLX_F_VALIDATION) && RARE(nan_hit(to_d3(acc)))) acc = to_v3(nan_guard(to_d3(acc), 50.0));
+                ivel_n = ivel + acc * HOT(c.dt);
             }
+            ivel = ivel_n;
             ipos = ipos + ivel * HOT(c.dt);                                              // :934
             {
                 float wn = snorm3(ang);                                             // :940-956
@@ -472,8 +488,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             auto missile_step = [&](V3& mpos, V3& mvel, const D3& z_ev) {
                 float mrho = 1.225f, msos = 343.f;
                 if (HAS(HLX_F_ATMOSPHERE)) atmosphere(fmaxf(mpos.z, 0.f), (float)T0, mrho, msos, &s_pow);
-                D3 sum;                                                             // drag + gravity, before evasion
-                if (w64) {
+                D3 sum = d3(0., 0., 0.);                                            // drag + gravity, before evasion
+                if (simple_wind) {
                     D3 va = to_d3(mvel) - wind;
                     D3 md;
                     if (HAS(HLX_F_MACH_DRAG) && dnorm(va) > 1e-6) md = mach_drag_force64(va, mrho, msos, 2.0, dp) * ((0.3 * 1.5) / 0.3) * (1.0 / 1000.0);
@@ -483,7 +499,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                         md = d3((c2 * va.x) * (1.0 / 1000.0), (c2 * va.y) * (1.0 / 1000.0), (c2 * va.z) * (1.0 / 1000.0));
                     }
                     sum = d3(md.x, md.y, md.z + (double)GRAV);
-                } else {
+                }
+                if (RARE(!w64)) {
                     V3 va = mvel - to_v3(wind);
                     V3 md;
                     if (HAS(HLX_F_MACH_DRAG) && snorm3(va) > 1e-6f)                  // :1087-1096
@@ -497,9 +514,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 }
                 if (HAS(HLX_F_EVASION))                                             // :1103-1108 (float64)
                     sum = d3(sum.x + z_ev.x * 2.0, sum.y + z_ev.y * 2.0, sum.z + z_ev.z * 2.0);
-                if (HAS(HLX_F_VALIDATION)) sum = nan_guard(sum, 20.0);
-                mvel = v3((float)((double)mvel.x + sum.x * HOT(c.dt64)), (float)((double)mvel.y + sum.y * HOT(c.dt64)),
-                          (float)((double)mvel.z + sum.z * HOT(c.dt64)));                // :1116
+                V3 mvel_n = v3((float)((double)mvel.x + sum.x * HOT(c.dt64)), (float)((double)mvel.y + sum.y * HOT(c.dt64)),
+                               (float)((double)mvel.z + sum.z * HOT(c.dt64)));           // :1116
+                asm volatile("" : "+v"(mvel_n.x), "+v"(mvel_n.y), "+v"(mvel_n.z));   // (pinned here: otherwise sunk into an else branch, in line)
+                if (HAS(HLX_F_VALIDATION) && RARE(nan_hit(sum))) {                  // :1111-1113, out of line
+                    sum = nan_guard(sum, 20.0);
+                    mvel_n = v3((float)((double)mvel.x + sum.x * HOT(c.dt64)), (float)((double)mvel.y + sum.y * HOT(c.dt64)),
+                                (float)((double)mvel.z + sum.z * HOT(c.dt64)));
+                    asm volatile("" : "+v"(mvel_n.x), "+v"(mvel_n.y), "+v"(mvel_n.z));
+                }
+                mvel = mvel_n;
                 mpos = mpos + mvel * HOT(c.dt);                                          // :1117
             };
             if (HAS(HLX_F_VOLLEY)) {                                                // :631-636: every ACTIVE missile
@@ -601,17 +625,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 if (all_inactive || fuze) terminated = true;
             } else if (HAS(HLX_F_PRECISION)) {                                      // :752-767
                 if (ground) { terminated = true; hit_target = near_target; }
-            } else {                                                                // :769-786
-                if (intercepted) terminated = true;
-                else if (ground) { terminated = true; hit_target = near_target; }
+            } else {                                                                // :769-786 (selects, not branches)
+                terminated = intercepted || ground;
+                hit_target = !intercepted && ground && near_target;
             }
-            if (ipos.z < 0.f) terminated = true;                                    // :789-811
-            else if (fuel <= 0.f) terminated = true;
-            else if (steps > 1000) {
-                if (distance > last_distance) worsening = min(worsening + 1, 0xFFF);
-                else worsening = max(0, worsening - 5);
-                last_distance = distance;
-                if (worsening > 500 && distance > 2500.f) terminated = true;
+            {                                                                       // :789-811, the elif chain as selects
+                const bool crash = ipos.z < 0.f, dry = fuel <= 0.f;
+                const bool late = !crash && !dry && steps > 1000;
+                const int w_next = (distance > last_distance) ? min(worsening + 1, 0xFFF) : max(0, worsening - 5);
+                worsening = late ? w_next : worsening;
+                last_distance = late ? distance : last_distance;
+                terminated = terminated || crash || dry || (late && worsening > 500 && distance > 2500.f);
             }
             truncated = steps >= HOT(c.max_steps);                                       // :813-814
             STAMP(6);   // wind + termination
@@ -646,20 +670,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     reward = reward - 0.2f;
                     prev_distance = distance;
                 }
-            } else if (intercepted) {                                               // :1274-1282
-                reward = (float)(5000.0 + (double)(HOT(c.max_steps) - steps) * 0.5);
-            } else if (terminated) {                                                // :1284-1296
-                reward = fmaxf(-distance * 0.5f, -2000.f);
-                if (hit_target) reward -= 1000.f;
-                else if (ipos.z < 0.f) reward -= 500.f;
-                else if (fuel <= 0.f) reward -= 300.f;
-            } else {                                                                // :1298-1320
+            } else {
+                // per-step shaping (:1298-1320) for every lane; the terminal forms (:1274-1296) override it for the few that end
                 float delta = prev_distance - distance;
                 float cv = divc(delta, HOT(c.inv_dtf));
                 reward = clampf(divc(cv, 1.0 / 100.0), -0.5f, 2.0f) * 0.3f;
                 reward = reward + delta * ((distance < 200.f) ? 2.0f : (distance < 500.f) ? 1.0f : 0.5f);
                 reward = reward - 0.5f;
-                prev_distance = distance;
+                const bool ending = intercepted || terminated;
+                if (RARE(ending)) {
+                    float rt = fmaxf(-distance * 0.5f, -2000.f);                    // :1284-1296
+                    rt -= hit_target ? 1000.f : (ipos.z < 0.f) ? 500.f : (fuel <= 0.f) ? 300.f : 0.f;
+                    reward = intercepted ? (float)(5000.0 + (double)(HOT(c.max_steps) - steps) * 0.5) : rt;   // :1274-1282
+                }
+                prev_distance = ending ? prev_distance : distance;
             }
             done = terminated || truncated;
             ep_return += reward;
@@ -682,7 +706,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             reward_out[i] = reward;
             term_out[i] = terminated ? 1 : 0;
             trunc_out[i] = truncated ? 1 : 0;
-            if (slots & (1u << 20)) {   // some hlx_info_soa plane is wanted (one SGPR test instead of nine pointer fetches)
+            if (RARE(slots & (1u << 20))) {   // some hlx_info_soa plane is wanted (one SGPR test instead of nine pointer fetches)
             if (HOT(opt.info.distance)) HOT(opt.info.distance)[i] = distance;
             if (HOT(opt.info.min_distance)) HOT(opt.info.min_distance)[i] = min_distance;
             if (HOT(opt.info.fuel)) HOT(opt.info.fuel)[i] = fuel;
@@ -731,8 +755,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         // trip through the observation code.  Outputs are bit-identical either way (bench.py's self-check compares the
         // two forms: the big batch runs single-pass through hlx_rollout, its slabs two-pass through hlx_step).
         const bool single = MODE == 0 && HOT(opt.terminal_obs) == nullptr && !(slots & (1u << 20));
+        // A do-while whose back edge is the rare direction (second trip only when a terminal observation is wanted AND some
+        // lane of the wave finished): the common step falls out of the loop without a taken branch.
+        int pass = (MODE == 0 ? 0 : 1);
+        bool again;
 #pragma unroll 1
-        for (int pass = (MODE == 0 ? 0 : 1); pass < 2; ++pass) {
+        do {
             STAMP2(1);  // close-up: loop top
             bool fresh = false;      // this lane has just respawned: its observation is the first of a new episode
             // `rsalt` is an opaque zero defined inside the respawn pass: the respawn draws are pure functions of
@@ -750,9 +778,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             float rd[RS_ITEMS][4];
 #pragma unroll
             for (int j = 0; j < RS_ITEMS; ++j) rd[j][0] = rd[j][1] = rd[j][2] = rd[j][3] = 0.f;
-            if (pass == 1 && single) break;
             const unsigned long long dmask = (pass == 1 || single) ? __ballot(done) : 0ull;
-            if (pass == 1 && __builtin_expect(dmask == 0ull, 1)) break;
             if (RARE(dmask != 0ull)) {
                 asm volatile("" : "+v"(rsalt));
                 const bool wide = (n - (int)blockIdx.x * 64) >= RS_ITEMS;      // lanes 0..10, the ones that serve, are live
@@ -1263,7 +1289,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 row[25] = fusion;                                                   // :1030
                 STAMP(12);  // 26-D observation formulas -> LDS row
             }
-        }
+            again = pass == 0 && !single && __ballot(done) != 0ull;
+            ++pass;
+        } while (RARE(again));
 
         STAMP(13);  // observation passes (incl. loop exit)
         // ---------------------------------------------------------------------- store state + rings
