@@ -307,18 +307,19 @@ DEV void atmosphere(float alt, float T0, float& rho, float& sos, const PowTab* t
     constexpr float R = 287.05f, G = 9.80665f, L = 0.0065f;
     constexpr float EXPO = (float)(9.80665 / (287.05 * 0.0065));
     constexpr float GAMMA_R = (float)(1.4 * 287.05);
-    float T, P;
-    if (alt <= 11000.0f) {
-        T = T0 - L * alt;                         // :70-71
-        P = 101325.0f * pow_ref(HLX_DIVF(T, T0), EXPO, tab);   // :95-100
-    } else if (alt <= 20000.0f) {                 // :72-74,102-108 (not reachable in shipped scenarios)
-        T = 216.65f;
-        P = 22632.0f * exp_np((-G * (alt - 11000.0f)) / (float)(287.05 * 216.65));
-    } else {                                      // :76-78,110-113
-        float ex = alt - 20000.0f;
-        T = 216.65f * exp_np(-ex / 10000.0f);
-        const float Pb = 5474.790039909648f;      // 22632 * exp(-g*9000/(R*216.65))  (:112)
-        P = Pb * exp_np(-ex / 6000.0f);
+    // troposphere for every lane; the upper layers (not reachable in the shipped scenarios) override it out of line
+    float T = T0 - L * alt;                       // :70-71
+    float P = 101325.0f * pow_ref(HLX_DIVF(T, T0), EXPO, tab);   // :95-100
+    if (__builtin_expect(alt > 11000.0f, 0)) {
+        if (alt <= 20000.0f) {                    // :72-74,102-108
+            T = 216.65f;
+            P = 22632.0f * exp_np((-G * (alt - 11000.0f)) / (float)(287.05 * 216.65));
+        } else {                                  // :76-78,110-113
+            float ex = alt - 20000.0f;
+            T = 216.65f * exp_np(-ex / 10000.0f);
+            const float Pb = 5474.790039909648f;  // 22632 * exp(-g*9000/(R*216.65))  (:112)
+            P = Pb * exp_np(-ex / 6000.0f);
+        }
     }
     rho = HLX_DIVF(P, R * T);                     // :166
     sos = HLX_SQRTF(GAMMA_R * T);                     // :167-169
@@ -331,29 +332,33 @@ struct DragParams {
 // physics_models.py:236-264  drag force vector (float32 velocity); `area` = reference_area
 DEV V3 mach_drag_force(V3 v, float rho, float sos, float area, const DragParams& p) {
     float vm = snorm3(v);
-    if (vm < 1e-6f) return v3(0.f, 0.f, 0.f);
     float mach = HLX_DIVF(vm, sos);                                          // :233-234
-    float cd;
-    if (mach < p.subsonic) cd = p.base_cd;                                  // :207-209
-    else if (mach < p.supersonic) {
-        float frac = HLX_DIVF(mach - p.subsonic, p.mach_span);              // :213-214
-        cd = p.base_cd * (1.0f + p.peak_m1 * frac);                         // :215-216 ((peak - 1.0) is a Python-float expression)
-    } else cd = p.cd_super;                                                 // :220 (python-float product)
+    float cd = p.base_cd;                                                   // :207-209 subsonic; the other regimes out of line
+    if (__builtin_expect(!(mach < p.subsonic), 0)) {
+        if (mach < p.supersonic) {
+            float frac = HLX_DIVF(mach - p.subsonic, p.mach_span);          // :213-214
+            cd = p.base_cd * (1.0f + p.peak_m1 * frac);                     // :215-216 ((peak - 1.0) is a Python-float expression)
+        } else cd = p.cd_super;                                             // :220 (python-float product)
+    }
     float a = (((0.5f * rho) * (vm * vm)) * cd) * area;                     // :258
-    return V3{HLX_DIVF(-v.x, vm) * a, HLX_DIVF(-v.y, vm) * a, HLX_DIVF(-v.z, vm) * a};   // :262-264
+    V3 f = V3{HLX_DIVF(-v.x, vm) * a, HLX_DIVF(-v.y, vm) * a, HLX_DIVF(-v.z, vm) * a};   // :262-264
+    if (__builtin_expect(vm < 1e-6f, 0)) f = v3(0.f, 0.f, 0.f);             // :238-239 (an override, not an early return: out of line)
+    return f;
 }
 // the same with a float64 air-relative velocity (Mach model on, simple float64 wind): generic kernel only
 DEV D3 mach_drag_force64(D3 v, float rho, float sos, double area, const DragParams& p) {
     double vm = dnorm(v);
-    if (vm < 1e-6) return d3(0., 0., 0.);
     double mach = vm / (double)sos;
-    double cd;
-    if (mach < (double)p.subsonic) cd = p.base_cd;
-    else if (mach < (double)p.supersonic)
-        cd = (double)p.base_cd * (1.0 + (double)p.peak_m1 * ((mach - (double)p.subsonic) / ((double)p.supersonic - (double)p.subsonic)));
-    else cd = (double)p.cd_super;
+    double cd = p.base_cd;
+    if (__builtin_expect(!(mach < (double)p.subsonic), 0)) {
+        if (mach < (double)p.supersonic)
+            cd = (double)p.base_cd * (1.0 + (double)p.peak_m1 * ((mach - (double)p.subsonic) / ((double)p.supersonic - (double)p.subsonic)));
+        else cd = (double)p.cd_super;
+    }
     double a = ((((double)(0.5f * rho)) * (vm * vm)) * cd) * area;
-    return D3{(-v.x / vm) * a, (-v.y / vm) * a, (-v.z / vm) * a};
+    D3 f = D3{(-v.x / vm) * a, (-v.y / vm) * a, (-v.z / vm) * a};
+    if (__builtin_expect(vm < 1e-6, 0)) f = d3(0., 0., 0.);
+    return f;
 }
 // environment.py:927-930 / 1111-1113 nan_to_num(nan=0, +-inf=+-lim), applied when any component is non-finite
 DEV bool nan_hit(D3 a) {   // |x| + |y| + |z| is finite exactly when all three are (no cancellation between non-negative terms)

@@ -459,9 +459,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             }
             if (RARE(!w64)) {
                 V3 va = ivel - to_v3(wind);
-                V3 dacc;
-                if (HAS(HLX_F_MACH_DRAG) && snorm3(va) > 1e-6f) dacc = divc(mach_drag_force(va, rho, sos, 1.0f, dp), 1.0 / 500.0);
-                else {
+                V3 dacc = v3(0.f, 0.f, 0.f);
+                if (HAS(HLX_F_MACH_DRAG)) dacc = divc(mach_drag_force(va, rho, sos, 1.0f, dp), 1.0 / 500.0);
+                if (!HAS(HLX_F_MACH_DRAG) || RARE(!(snorm3(va) > 1e-6f))) {         // :920 simple drag (Mach model off, or no air speed)
                     float c1 = HAS(HLX_F_ATMOSPHERE) ? (-0.15f * rho) : (float)(-0.5 * 0.3 * 1.225);
                     float c2 = c1 * snorm3(va);
                     dacc = divc(va * c2, 1.0 / 500.0);
@@ -502,10 +502,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 }
                 if (RARE(!w64)) {
                     V3 va = mvel - to_v3(wind);
-                    V3 md;
-                    if (HAS(HLX_F_MACH_DRAG) && snorm3(va) > 1e-6f)                  // :1087-1096
-                        md = divc(mach_drag_force(va, mrho, msos, 2.0f, dp) * 1.5f, 1.0 / 1000.0);
-                    else {
+                    V3 md = v3(0.f, 0.f, 0.f);
+                    if (HAS(HLX_F_MACH_DRAG)) md = divc(mach_drag_force(va, mrho, msos, 2.0f, dp) * 1.5f, 1.0 / 1000.0);   // :1087-1096
+                    if (!HAS(HLX_F_MACH_DRAG) || RARE(!(snorm3(va) > 1e-6f))) {
                         float c1 = HAS(HLX_F_ATMOSPHERE) ? (-0.15f * mrho) : (float)(-0.5 * 0.3 * 1.225);
                         float c2 = c1 * snorm3(va);
                         md = divc(va * c2, 1.0 / 1000.0);
@@ -535,12 +534,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             // -------------------------------------------------------------- wind (environment.py:1119-1129)
             if (HAS(HLX_F_ENH_WIND)) {                                              // physics_models.py:351-387
                 float walt = fmaxf(ipos.z, 0.f);
-                float prof, ti;
+                // boundary-layer formulas for every lane (the power law of a lane at or below 10 m is computed and discarded);
+                // the surface layer as selects, the free atmosphere above the boundary layer out of line
+                float prof = pow_ref(divc(fmaxf(walt, 10.f), 1.0 / 10.0), 0.143f, &s_pow);    // :319-324
+                float ti = HOT(c.ti_mid) * (1.0f - (walt / HOT(c.bl_height)) * 0.7f);         // :343-346
                 if (walt <= 10.f) { prof = 1.0f; ti = HOT(c.ti_low); }
-                else if (walt <= HOT(c.bl_height)) {
-                    prof = pow_ref(divc(walt, 1.0 / 10.0), 0.143f, &s_pow);                    // :319-324
-                    ti = HOT(c.ti_mid) * (1.0f - (walt / HOT(c.bl_height)) * 0.7f);           // :343-346
-                } else { prof = HOT(c.bl_prof); ti = HOT(c.ti_high); }
+                if (RARE(walt > HOT(c.bl_height))) { prof = HOT(c.bl_prof); ti = HOT(c.ti_high); }
                 V3 w = v3(HOT(c.base_wind[0]) * prof, HOT(c.base_wind[1]) * prof, HOT(c.base_wind[2]) * prof);
                 const D3 z = z_wind;
                 const double gu = u_gust;

@@ -43,6 +43,18 @@ for t in range(40):
     add("steps <= 1", steps <= 1); add("steps <= 5 (ground ring filling)", steps <= 5); add("steps > 1000", steps > 1000)
     add("done this step", done); add("closing > 0 (obs[13] != -1)", o[:, 13] != -1.0)
     add("fuel == 0", o[:, 12] == 0.0)
+    # physics regimes (v2 models): altitude bands of the atmosphere / wind profile, Mach bands of the drag model
+    buf = np.frombuffer(st, dtype=np.uint8).reshape(n, -1)
+    f32 = buf[:, :19 * 4].view(np.float32)          # int_pos 0-2, int_vel 3-5, quat 6-9, fuel 10, thrust 11-13, mis_pos 14-16, mis_vel 17-19
+    f32b = buf[:, :20 * 4].view(np.float32)
+    iz, mz = f32b[:, 2], f32b[:, 16]
+    isp = np.linalg.norm(f32b[:, 3:6], axis=1); msp = np.linalg.norm(f32b[:, 17:20], axis=1)
+    add("interceptor z <= 10", iz <= 10); add("interceptor 10 < z <= 1000", (iz > 10) & (iz <= 1000)); add("interceptor z > 1000", iz > 1000)
+    add("interceptor z > 11000", iz > 11000); add("missile z > 11000", mz > 11000)
+    for nm, sp in (("interceptor", isp), ("missile", msp)):
+        m = sp / 340.0
+        add(nm + " Mach < 0.8", m < 0.8); add(nm + " 0.8 <= Mach < 1.2", (m >= 0.8) & (m < 1.2)); add(nm + " Mach >= 1.2", m >= 1.2)
+        add(nm + " speed < 1e-6", sp < 1e-6)
 print(f"{'predicate':42s} {'envs':>8s} {'waves any':>10s} {'waves all':>10s}")
 for k, (a, b, c, m) in acc.items():
     print(f"{k:42s} {a / m:8.4f} {b / m:10.4f} {c / m:10.4f}")
