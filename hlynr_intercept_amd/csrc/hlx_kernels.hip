@@ -998,11 +998,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     if (on_det && cb < cthr) { on_det = false; on_why = -2.f; }
                 }
                 STAMP2(5);  // close-up: beam angle (acosf)
-                if (on_det) {                                                       // :559-566
+                {                                                                   // :559-566 (straight-line: selects, not a divergent block)
                     float aq = (HOT(c.radar_quality) * (1.0f - (range * HOT(c.inv_radar_range)) * 0.5f)) * HOT(cur.on_rel);
-                    if (RARE(fabsf(n_on - aq) < 2e-6f))   // Bernoulli draw within a few ulps of the probability: the reference's own division
+                    if (RARE(on_det && fabsf(n_on - aq) < 2e-6f))   // Bernoulli draw within a few ulps of the probability: the reference's own division
                         aq = (HOT(c.radar_quality) * (1.0f - HLX_DIVF(range, HOT(c.radar_range)) * 0.5f)) * HOT(cur.on_rel);
-                    if (n_on > aq) { on_det = false; on_why = -3.f; }
+                    const bool miss = on_det && n_on > aq;
+                    on_det = on_det && !miss;
+                    on_why = miss ? -3.f : on_why;
                 }
                 STAMP2(6);  // close-up: Bernoulli
                 V3 d_on = rel;
@@ -1030,20 +1032,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     float grange = fnorm(g2m);
                     if (RARE(fabsf(grange - HOT(c.g_max_range)) < 0.05f)) grange = snorm3(g2m);
                     g_det = !(grange > HOT(c.g_max_range));                              // :396
-                    if (g_det && grange > 1e-6f) {                                  // :401-406  arcsin(s) against the elevation window:
-                        // s against the float32 values at which the host's asinf crosses the two limits (hlx_host.inc)
+                    {                                                               // :401-406  arcsin(s) against the elevation window:
+                        // s against the float32 values at which the host's asinf crosses the two limits (hlx_host.inc); straight-line
+                        const bool chk = g_det && grange > 1e-6f;
                         float se = clampf(g2m.z * __builtin_amdgcn_rcpf(grange), -1.f, 1.f);
-                        if (RARE(fminf(fabsf(se - HOT(c.sin_min_elev)), fabsf(se - HOT(c.sin_max_elev))) < 4e-6f))
+                        if (RARE(chk && fminf(fabsf(se - HOT(c.sin_min_elev)), fabsf(se - HOT(c.sin_max_elev))) < 4e-6f))
                             se = clampf(HLX_DIVF(g2m.z, snorm3(g2m)), -1.f, 1.f);
-                        if (se < HOT(c.sin_min_elev) || se > HOT(c.sin_max_elev)) g_det = false;
+                        g_det = g_det && !(chk && (se < HOT(c.sin_min_elev) || se > HOT(c.sin_max_elev)));
                     }
-                    if (mpos.z < 50.f) g_det = false;                               // :409
-                    if (g_det) {                                                    // :413-418
-                        float dpq = ((HOT(c.g_base_q) * (1.0f - (grange * HOT(c.inv_g_max_range)) * 0.4f)) * HOT(c.weather)) * HOT(cur.g_rel);
-                        if (RARE(fabsf(n_g - dpq) < 2e-6f))
-                            dpq = ((HOT(c.g_base_q) * (1.0f - HLX_DIVF(snorm3(g2m), HOT(c.g_max_range)) * 0.4f)) * HOT(c.weather)) * HOT(cur.g_rel);
-                        if (n_g > dpq) g_det = false;
-                        else {
+                    g_det = g_det && !(mpos.z < 50.f);                              // :409
+                    float dpq = ((HOT(c.g_base_q) * (1.0f - (grange * HOT(c.inv_g_max_range)) * 0.4f)) * HOT(c.weather)) * HOT(cur.g_rel);   // :413-418
+                    if (RARE(g_det && fabsf(n_g - dpq) < 2e-6f))
+                        dpq = ((HOT(c.g_base_q) * (1.0f - HLX_DIVF(snorm3(g2m), HOT(c.g_max_range)) * 0.4f)) * HOT(c.weather)) * HOT(cur.g_rel);
+                    g_det = g_det && !(n_g > dpq);
+                    if (g_det) {
+                        {
                             // :422-429 float64 measurement (kept float64 through the delay ring: the Kalman
                             // velocity estimate is tiny while detections are continuous, so outputs such as the
                             // lead-angle cosine are sensitive to 1e-4 m of measurement rounding)
@@ -1077,23 +1080,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 // ---- datalink (core.py:440-474)
                 float datalink = 0.f;
                 if (HAS(HLX_F_GROUND)) {
-                    float lr = fnorm_out(ipos - gp);
-                    if (!(lr > HOT(c.max_datalink)) && !(n_dl < HOT(c.packet_loss))) {
-                        float x = lr * HOT(c.inv_max_datalink);
-                        float vr = fnorm_out(ivel) * 0.001f;
-                        float dop = (0.3f < vr) ? (float)(1.0 - 0.3) : (1.0f - vr);
-                        datalink = clampf(((1.0f - x * x) * dop) * 0.95f, 0.f, 1.f);
-                    }
+                    const float lr = fnorm_out(ipos - gp);                           // (pure output; straight-line)
+                    const float x = lr * HOT(c.inv_max_datalink);
+                    const float vr = fnorm_out(ivel) * 0.001f;
+                    const float dop = (0.3f < vr) ? (float)(1.0 - 0.3) : (1.0f - vr);
+                    const float dl = clampf(((1.0f - x * x) * dop) * 0.95f, 0.f, 1.f);
+                    datalink = (!(lr > HOT(c.max_datalink)) && !(n_dl < HOT(c.packet_loss))) ? dl : 0.f;
                 }
                 // ---- fusion confidence (core.py:476-509) - pure output
-                float fusion;
-                if (!d_on_det && !d_g_det) fusion = 0.f;
-                else if (!d_g_det) fusion = (float)(HOT(c.radar_quality64) * 0.5);
-                else if (!d_on_det) fusion = d_gq * 0.6f;
-                else {
-                    float agree = 1.0f - fminf(fnorm_out(d_on - d_gp) * 0.005f, 1.0f);
-                    fusion = clampf((float)(0.35 * HOT(c.radar_quality64)) + 0.50f * d_gq + 0.15f * agree, 0.f, 1.f);
-                }
+                const float agree = 1.0f - fminf(fnorm_out(d_on - d_gp) * 0.005f, 1.0f);
+                const float f_both = clampf((float)(0.35 * HOT(c.radar_quality64)) + 0.50f * d_gq + 0.15f * agree, 0.f, 1.f);
+                const float fusion = d_g_det ? (d_on_det ? f_both : d_gq * 0.6f) : (d_on_det ? (float)(HOT(c.radar_quality64) * 0.5) : 0.f);
                 if (!fresh) {
                     // bit 7: a delayed onboard sample exists (core.py:576-593): info['radar_quality'] is the configured quality then,
                     // detected or not, and 0.0 only while the delay line is still filling
