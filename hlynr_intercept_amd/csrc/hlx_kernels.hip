@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             }
         }
 
-        float reward = 0.f, distance = 0.f;
+        float reward = 0.f, distance = 0.f, range_c = 0.f;   // range_c: ||missile - interceptor|| of the state the observation will see
         bool terminated = false, truncated = false, intercepted = false, hit_target = false, fuze = false,
              clamped = false;
 
@@ -407,10 +407,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 at = (lu * at.x + h * at.y) + v * at.z;                             // :1052-1056
             }
             if (RARE(fuel <= 0.f)) { at = at * 0.f; clamped = true; }                      // core.py:1080-1083
-            float am = snorm3(at);
-            if (RARE(am > 50.f)) { at = at * HLX_DIVF(50.f, am); clamped = true; }                // core.py:1086-1090
-            float gm = snorm3(aw);
-            if (RARE(gm > 5.f)) { aw = aw * HLX_DIVF(5.f, gm); clamped = true; }                  // core.py:1094-1098
+            // core.py:1086-1098: ||a|| <= sqrt(3) max|a_i|, so the exact norms (numpy's float32 norm: ~20 instructions each)
+            // are formed only when a component is large enough for a limit to be within reach (28 sqrt(3) < 50, 2.8 sqrt(3) < 5);
+            // with actions in [-1, 1] that is never
+            if (RARE(fmaxf(fmaxf(fabsf(at.x), fabsf(at.y)), fabsf(at.z)) > 28.f)) {
+                float am = snorm3(at);
+                if (am > 50.f) { at = at * HLX_DIVF(50.f, am); clamped = true; }                  // core.py:1086-1090
+            }
+            if (RARE(fmaxf(fmaxf(fabsf(aw.x), fabsf(aw.y)), fabsf(aw.z)) > 2.8f)) {
+                float gm = snorm3(aw);
+                if (gm > 5.f) { aw = aw * HLX_DIVF(5.f, gm); clamped = true; }                    // core.py:1094-1098
+            }
 
             // Is the reference's wind a float64 array at this point?  Simple wind: float32 copy of
             // base_wind after reset, float64 from the first update on (environment.py:542,1127-1129).
@@ -585,6 +592,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             // -------------------------------------------------------------- intercept / termination (:657-814)
             V3 rel = mpos - ipos;
             distance = snorm3(rel);
+            range_c = distance;
             if (HAS(HLX_F_VOLLEY)) {                                                // :661-692
                 const float thr = HAS(HLX_F_PROX_FUZE) ? HOT(c.kill_radius) : HOT(cur.radius);
                 intercepted = false;
@@ -607,7 +615,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             if (HAS(HLX_F_PROX_FUZE) && min_distance < HOT(c.kill_radius)) { fuze = true; intercepted = true; } // :715-717
             const bool ground = mpos.z <= 0.f;
             const float gdx = mpos.x - HOT(c.target[0]), gdy = mpos.y - HOT(c.target[1]);
-            const bool near_target = HLX_SQRTF((float)((double)(gdx * gdx) + (double)(gdy * gdy))) < 500.f;
+            bool near_target = false;                                               // only a missile on the ground asks (rare)
+            if (HAS(HLX_F_VOLLEY) || RARE(ground)) near_target = HLX_SQRTF((float)((double)(gdx * gdx) + (double)(gdy * gdy))) < 500.f;
             if (HAS(HLX_F_VOLLEY)) {                                                // :724-748
                 bool all_inactive = true;
 #pragma unroll
@@ -898,6 +907,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                               (float)(COLD(int_lo[2]) + COLD(int_span[2]) * u[6]));         // :445
                     V3 rel0 = mpos - ipos;
                     float reld = snorm3(rel0);
+                    range_c = reld;                                                 // (non-volley: the observation's own range)
                     if (HAS(HLX_F_TOWARD_MISSILE) && reld > 1e-6f)                  // :452-462
                         ivel = (rel0 / reld) * (float)(COLD(int_speed[0]) + COLD(int_speed[1]) * u[7]);
                     else                                                            // :467
@@ -981,7 +991,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 }
                 STAMP2(2);  // close-up: draws selected
                 const V3 rel = mpos - ipos;
-                const float range = snorm3(rel);
+                // ||missile - interceptor|| is at hand: the step's `distance`, or the spawn distance of a lane that has just respawned
+                const float range = (HAS(HLX_F_VOLLEY) || MODE != 0) ? snorm3(rel) : range_c;
                 bool on_det = !(range > HOT(c.radar_range));                             // :539
                 float on_why = on_det ? 0.f : -1.f;   // detection_info['reason'] (:541,:555,:566), carried through the delay ring
                 STAMP2(3);  // close-up: range

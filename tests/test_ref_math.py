@@ -87,3 +87,32 @@ def test_device_copies_equal_the_oracle_copies():
         ref = np.empty_like(x)
         L.orc_np_expf_batch(x.ctypes.data, ref.ctypes.data, len(x))
         assert np.array_equal(gpu(1, x).view(np.uint32), ref.view(np.uint32)), start
+
+
+@pytest.mark.gpu
+def test_short_square_roots_equal_the_compilers_own():
+    """hlx_device.h sqrt_rn (float32) on EVERY float from 2^-100 up, on 0 and on +inf, and dsqrt_pos (float64) on 2^27 sums of
+    products spread over the magnitudes the step forms, against the compiler's IEEE sqrtf / sqrt on the device, bit for bit
+    (hlx_selftest_math kinds 2 and 3 answer 1.0 where the bits agree)."""
+    import torch
+    from hlynr_intercept_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+
+    def agree(kind, xd, y=0.0):
+        out = torch.empty_like(xd)
+        _lib.check(lib.hlx_selftest_math(kind, xd.data_ptr(), float(y), out.data_ptr(), xd.numel(), None))
+        return bool((out == 1.0).all().item())
+
+    lo, hi = _bits(2.0 ** -100), 0x7F800000          # ... +inf included
+    step = 1 << 26
+    for start in range(lo, hi + 1, step):
+        x = torch.arange(start, min(start + step, hi + 1), dtype=torch.int64, device=dev).to(torch.int32).view(torch.float32)
+        assert agree(2, x), hex(start)
+    assert agree(2, torch.zeros(64, device=dev))
+    g = torch.Generator(device=dev).manual_seed(5)
+    for scale in (1e-3, 1.0, 30.0, 3e2, 3e3, 1e5):
+        x = (torch.rand(1 << 24, generator=g, device=dev) * 2 - 1) * scale
+        for y in (0.0, 1e-3, 7.5, -0.3 * scale, 1e4):
+            assert agree(3, x, y), (scale, y)
+    assert agree(3, torch.zeros(64, device=dev), 0.0)
