@@ -206,9 +206,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
     // ------------------------------------------------------------------ first load batch, issued at entry
     // (the integrator's state groups and the action row); the Philox draws below do not depend on them and run
     // while the loads are in flight.  The Kalman groups and the ring sample follow as a second batch after Philox.
-    float4 g_ipos = A[G_IPOS * 64], g_ivel = A[G_IVEL * 64], g_quat = A[G_QUAT * 64], g_mpos = A[G_MPOS * 64];
-    float4 g_mvel = A[G_MVEL * 64], g_w1 = A[G_W1 * 64];
+    float4 g_ipos = A[G_IPOS * 64], g_ivel = A[G_IVEL * 64], g_quat = A[G_QUAT * 64], g_w1 = A[G_W1 * 64];
     double2 g_w0 = AD[G_W0 * 64];
+    float4 g_mpos = A[G_MPOS * 64], g_mvel = A[G_MVEL * 64];   // first needed a whole integrator section later than the others
     float4 g_thr = make_float4(0.f, 0.f, 0.f, 0.f), g_misc = g_thr;
     if (HAS(HLX_F_THRUST_LAG) || HAS(HLX_F_DOMAIN_RAND)) g_thr = A[G_THRUST * 64];   // .w: a domain-randomised constant
     if (HAS(HLX_F_DOMAIN_RAND)) g_misc = A[G_MISC * 64];
@@ -335,7 +335,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             }
             if (!PERSIST) { g_kfp = A[G_KFP * 64 + late]; g_kf0 = AD[G_KF0 * 64 + late]; g_kf1 = AD[G_KF1 * 64 + late]; g_kf2 = AD[G_KF2 * 64 + late]; }
         }
-        PIN4(g_ipos); PIN4(g_ivel); PIN4(g_quat); PIN4(g_mpos); PIN4(g_mvel); PIN4(g_w1); PIN2(g_w0);
+        // The missile's groups are released (waited for) where the missile is integrated, a whole interceptor section later --
+        // unless something reads the missile earlier (LOS-frame actions, the volley's bookkeeping, a reset-only launch).
+        constexpr bool missile_late = MODE == 0 && !((SPEC & KF_DYNAMIC) != 0) && !(SPEC & (HLX_F_OBS_LOS | HLX_F_VOLLEY));
+        PIN4(g_ipos); PIN4(g_ivel); PIN4(g_quat); PIN4(g_w1); PIN2(g_w0);
+        if (!missile_late) { PIN4(g_mpos); PIN4(g_mvel); }
         if (HAS(HLX_F_THRUST_LAG) || HAS(HLX_F_DOMAIN_RAND)) PIN4(g_thr);
         if (HAS(HLX_F_DOMAIN_RAND)) PIN4(g_misc);
         PIN2(a01); PIN2(a23); PIN2(a45);
@@ -352,9 +356,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         STAMP(2);   // Philox block done (loads still in flight)
         V3 ipos = v3(g_ipos.x, g_ipos.y, g_ipos.z), ivel = v3(g_ivel.x, g_ivel.y, g_ivel.z);
         Quat q = Quat{g_quat.x, g_quat.y, g_quat.z, g_quat.w};
-        V3 mpos = v3(g_mpos.x, g_mpos.y, g_mpos.z), mvel = v3(g_mvel.x, g_mvel.y, g_mvel.z);
+        V3 mpos = v3(0.f, 0.f, 0.f), mvel = mpos;
+        if (!missile_late) { mpos = v3(g_mpos.x, g_mpos.y, g_mpos.z); mvel = v3(g_mvel.x, g_mvel.y, g_mvel.z); }
         D3 wind = d3(g_w0.x, g_w0.y, __hiloint2double(__float_as_int(g_w1.y), __float_as_int(g_w1.x)));
-        float fuel = g_ipos.w, prev_distance = g_ivel.w, min_distance = g_mpos.w, last_distance = g_mvel.w;
+        float fuel = g_ipos.w, prev_distance = g_ivel.w, min_distance = 0.f, last_distance = 0.f;
+        if (!missile_late) { min_distance = g_mpos.w; last_distance = g_mvel.w; }
         uint32_t packed = __float_as_uint(g_w1.z);
         float ep_return = g_w1.w;
         int steps = (int)(packed & 0x1FFFu), worsening = (int)((packed >> 13) & 0xFFFu);
@@ -532,6 +538,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 mvel = mvel_n;
                 mpos = mpos + mvel * HOT(c.dt);                                          // :1117
             };
+            if (missile_late) {   // the missile's two groups: waited for here (they were loaded last)
+                PIN4(g_mpos); PIN4(g_mvel);
+                mpos = v3(g_mpos.x, g_mpos.y, g_mpos.z); mvel = v3(g_mvel.x, g_mvel.y, g_mvel.z);
+                min_distance = g_mpos.w; last_distance = g_mvel.w;
+            }
             if (HAS(HLX_F_VOLLEY)) {                                                // :631-636: every ACTIVE missile
 #pragma unroll
                 for (int k = 0; k < HLX_MAX_VOLLEY; ++k)
