@@ -337,7 +337,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         }
         // The missile's groups are released (waited for) where the missile is integrated, a whole interceptor section later --
         // unless something reads the missile earlier (LOS-frame actions, the volley's bookkeeping, a reset-only launch).
-        constexpr bool missile_late = MODE == 0 && !((SPEC & KF_DYNAMIC) != 0) && !(SPEC & (HLX_F_OBS_LOS | HLX_F_VOLLEY));
+        // (with the v2 models the second batch is long enough already: 11.40 against 11.46 us, profiles/r02_ab_missile_groups_waited_late.txt)
+        constexpr bool missile_late = MODE == 0 && !((SPEC & KF_DYNAMIC) != 0) && !(SPEC & (HLX_F_OBS_LOS | HLX_F_VOLLEY | HLX_F_ATMOSPHERE));
         PIN4(g_ipos); PIN4(g_ivel); PIN4(g_quat); PIN4(g_w1); PIN2(g_w0);
         if (!missile_late) { PIN4(g_mpos); PIN4(g_mvel); }
         if (HAS(HLX_F_THRUST_LAG) || HAS(HLX_F_DOMAIN_RAND)) PIN4(g_thr);
