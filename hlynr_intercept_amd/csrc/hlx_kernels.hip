@@ -795,11 +795,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             // pair) per finished lane instead of eleven in a row on the launch's critical tail.  Same keys and counters as
             // the per-lane form (kept for partial tail blocks and the parity instantiation), hence the same draws.
             constexpr int RS_ITEMS = 11;
-            float rd[RS_ITEMS][4];
-#pragma unroll
-            for (int j = 0; j < RS_ITEMS; ++j) rd[j][0] = rd[j][1] = rd[j][2] = rd[j][3] = 0.f;
+            // this pass's detection draws: the step's own, replaced INSIDE the respawn block by a fresh lane's first-observation
+            // draws (selecting them afterwards under `fresh` costs the common path nine copies and nine zero-initialisations)
+            float n_on = u_on, n_g = u_g;
+            double n_dl = u_dl;
+            D3 n_gp = z_gp, n_gv = z_gv;
             const unsigned long long dmask = (pass == 1 || single) ? __ballot(done) : 0ull;
             if (RARE(dmask != 0ull)) {
+                float rd[RS_ITEMS][4];
+#pragma unroll
+                for (int j = 0; j < RS_ITEMS; ++j) rd[j][0] = rd[j][1] = rd[j][2] = rd[j][3] = 0.f;
                 asm volatile("" : "+v"(rsalt));
                 const bool wide = (n - (int)blockIdx.x * 64) >= RS_ITEMS;      // lanes 0..10, the ones that serve, are live
                 if (!rnoise_buf) {
@@ -851,6 +856,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 }
                 if (done) {
                     fresh = true;
+                    if (rnoise_buf) {   // first observation of a new episode: its own draws
+                        const double* B = RN + 10 * N;
+                        n_on = (float)B[0]; n_g = (float)B[1 * N]; n_gp = d3(B[2 * N], B[3 * N], B[4 * N]);
+                        n_gv = d3(B[5 * N], B[6 * N], B[7 * N]); n_dl = B[8 * N];
+                    } else {   // items 3, 4, 5 = streams RS_RESET_OBS_U, RS_RESET_GPOS, RS_RESET_GVEL
+                        n_on = rd[3][0]; n_g = rd[3][1]; n_dl = (double)rd[3][2];
+                        n_gp = d3((double)rd[4][0], (double)rd[4][1], (double)rd[4][2]);
+                        n_gv = d3((double)rd[5][0], (double)rd[5][1], (double)rd[5][2]);
+                    }
                     if (MODE == 0 && pass == 1) {
                         if (HOT(opt.terminal_obs)) {
                             // the lane's row of the LDS tile (pass 0's observation of the terminal state) -> terminal_obs[i]: all
@@ -987,20 +1001,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             const bool act = (pass == 0) || done;
             if (act) {
                 // ======================================================== core.py:511-691 radar detection
-                float n_on = u_on, n_g = u_g;
-                double n_dl = u_dl;
-                D3 n_gp = z_gp, n_gv = z_gv;
-                if (fresh) {   // first observation of a new episode: its own draws
-                    if (rnoise_buf) {
-                        const double* B = RN + 10 * N;
-                        n_on = (float)B[0]; n_g = (float)B[1 * N]; n_gp = d3(B[2 * N], B[3 * N], B[4 * N]);
-                        n_gv = d3(B[5 * N], B[6 * N], B[7 * N]); n_dl = B[8 * N];
-                    } else {   // items 3, 4, 5 = streams RS_RESET_OBS_U, RS_RESET_GPOS, RS_RESET_GVEL
-                        n_on = rd[3][0]; n_g = rd[3][1]; n_dl = (double)rd[3][2];
-                        n_gp = d3((double)rd[4][0], (double)rd[4][1], (double)rd[4][2]);
-                        n_gv = d3((double)rd[5][0], (double)rd[5][1], (double)rd[5][2]);
-                    }
-                }
                 STAMP2(2);  // close-up: draws selected
                 const V3 rel = mpos - ipos;
                 // ||missile - interceptor|| is at hand: the step's `distance`, or the spawn distance of a lane that has just respawned
