@@ -571,7 +571,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     D3 gd; double e;
                     if (noise_buf) { gd = d3(SN[7 * N], SN[8 * N], SN[9 * N]); e = SN[10 * N]; }
                     else { V3 g; float ef; gust_draws(rng, g, ef); gd = to_d3(g); e = (double)ef; }
-                    double gn = dnorm(gd) + 1e-6, gmag = HOT(c.gust_scale) * e;
+                    // (the compiler's sqrt here, not dnorm's short sequence: with the short one in this rare block the v2dr kernel ran
+                    // 0.55 us slower per launch -- profiles/r02_ab_v2dr_gust_sqrt.txt)
+                    double gn = sqrt(ddot(gd, gd)) + 1e-6, gmag = HOT(c.gust_scale) * e;
                     w = v3((float)((double)w.x + (gd.x / gn) * gmag), (float)((double)w.y + (gd.y / gn) * gmag),
                            (float)((double)w.z + (gd.z / gn) * gmag));
                 }
