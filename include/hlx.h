@@ -263,7 +263,10 @@ int32_t hlx_get_load_schedule(const hlx_env *env);
 /* Diagnostics: evaluate the step kernel's restated transcendentals element-wise on device arrays (current device).
  * kind 0: out[i] = powf(x[i], y) as glibc computes it (physics_models.py:100,324 are `np.float32 ** float` = libm powf);
  * kind 1: out[i] = np.exp(np.float32 x[i]) as numpy's float32 kernel computes it (physics_models.py:78,105,113,
- * environment.py:1174-1180,1222).  tests/ compare both bit for bit with the oracle's copies. */
+ * environment.py:1174-1180,1222).  tests/ compare both bit for bit with the oracle's copies.
+ * kind 2: out[i] = 1.0 where the kernel's short correctly rounded float32 square root of x[i] has the bits of IEEE sqrtf,
+ * else 0.0; kind 3: the same for its short float64 square root on the argument |x[i] * y| + x[i] * x[i] (the norms
+ * np.linalg.norm forms at environment.py:910-921, 1087-1099).  tests/ require 1.0 everywhere (kind 2: every float). */
 int hlx_selftest_math(int32_t kind, const float *x, float y, float *out, int64_t n, void *stream);
 
 int32_t hlx_num_envs(const hlx_env *env);
