@@ -176,6 +176,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
     // generic variants read the feature flags at run time (one scalar load) -- except volley mode, whose K-missile loops
     // are compiled in or out: the generic variant comes with and without them (KF_DYNAMIC [| HLX_F_VOLLEY])
     const uint32_t FL = (SPEC & KF_DYNAMIC) ? ((P->hot.c.flags & ~(uint32_t)HLX_F_VOLLEY) | (SPEC & (uint32_t)HLX_F_VOLLEY)) : SPEC;
+    // The four output pointers are not among the preloaded SGPRs: one scalar load, first used far below.  With its only users
+    // in one later block the compiler sinks the load there, behind the Philox block, and its latency (~0.45 us) is exposed in
+    // full (tools/isa_tail_load.py; profiles/r02_ab_v2dr_gust_sqrt.txt).  A second, never-taken user at the very top of the kernel
+    // (before the state loads, so that everything below stays one block: placed behind them it split the entry block and cost the
+    // base kernel 0.45 us) keeps the load in the entry block -- issued first, landed long before it is needed -- at the price of
+    // one scalar compare.  profiles/r02_ab_kernarg_tail_load_pinned.txt: config presets 9.45 -> 8.65 us, base and v2dr unchanged.
+    if (RARE(n < 0)) asm volatile("" ::"s"(obs_out0), "s"(reward_out0), "s"(term_out0), "s"(trunc_out0));
     const int lane = threadIdx.x;
     const int i = blockIdx.x * 64 + lane;
     const bool live = i < n;
