@@ -146,9 +146,43 @@ def check(text):
     return len(starts), fail, info
 
 
+def tail_load_positions(text):
+    """{kernel: instructions from its start to the scalar load of the kernarg tail (the four output pointers, byte 56 on)}.
+    At entry that load's ~0.45 us hide behind the state loads and the Philox block; sunk to its first use behind the Philox
+    block they are exposed in full ("The kernarg tail").  None = no such load found."""
+    out, cur, n = {}, None, 0
+    for line in text.split("\n"):
+        m = re.match(r"^(?:[0-9a-f]+ <)?(_ZN\S*hlx_env_kernel\S*?)>?:", line)
+        if m:
+            cur, n = m.group(1), 0
+            out[cur] = None
+            continue
+        t = line.strip()
+        if cur is None or not t:
+            continue
+        if t.startswith((".end_amdhsa_kernel", ".section")) or re.match(r"^[0-9a-f]+ <", line):
+            cur = None
+            continue
+        if line.startswith(("\t", " ")) and not t.startswith((".", ";", "//", "s_nop")):   # (s_nop: the 256-byte preload header's padding)
+            n += 1
+            if out[cur] is None and t.startswith("s_load_dword") and re.search(r",\s*0x38\b", t.split("//")[0]):
+                out[cur] = n
+    return out
+
+
+TAIL_LOAD_LIMIT = 64     # instructions; every instantiation has it within its first ten today
+
+
 def verify(path=None):
-    """Raise if the library at `path` (default: the in-tree libhlx.so) reloads a hot word from scratch."""
-    n, fail, _ = check(listing(path))
+    """Raise if the library at `path` (default: the in-tree libhlx.so) reloads a hot word from scratch, or issues the
+    kernarg-tail load late in a single-step kernel."""
+    text = listing(path)
+    late = {k: v for k, v in tail_load_positions(text).items() if v is None or v > TAIL_LOAD_LIMIT}
+    if late and not os.environ.get("HLX_SKIP_TAIL_CHECK"):
+        raise RuntimeError("hotcheck: the scalar load of the output pointers is not issued at kernel entry (its latency would be "
+                           "exposed behind the Philox block; HLX_SKIP_TAIL_CHECK=1 to build anyway): "
+                           + "; ".join(f"{k[28:70]}... at {v}" for k, v in late.items()))
+    n, fail, _ = check(text)
     if n == 0:
         raise RuntimeError("hotcheck: no hlx_env_kernel instantiation found in the code object")
     if fail:

@@ -44,3 +44,16 @@ def test_built_library_keeps_hot_words_in_registers():
     lib = build.build()
     assert os.path.exists(lib)
     assert hotcheck.verify(lib) >= 20          # every hlx_env_kernel instantiation of the product library
+
+
+def test_kernarg_tail_load_sits_at_kernel_entry_in_every_instantiation():
+    """hotcheck.tail_load_positions: the scalar load of the output pointers within the first instructions of each env kernel
+    (sunk behind the Philox block it costs ~0.45-0.8 us per launch: DESIGN.md section 5, "The kernarg tail")."""
+    head = "_ZN12_GLOBAL__N_114hlx_env_kernelILj1ELi0ELb0EEEvv:\n"
+    tail = "\ts_load_dwordx8 s[36:43], s[0:1], 0x38\n\t.end_amdhsa_kernel\n"
+    late = head + "\tv_add_f32_e32 v1, v2, v3\n" * 80 + tail
+    assert list(hotcheck.tail_load_positions(late).values()) == [81]
+    early = head + "\ts_nop 0\n" * 59 + "\tv_add_f32_e32 v1, v2, v3\n" + tail      # the preload header's padding does not count
+    assert list(hotcheck.tail_load_positions(early).values()) == [2]
+    pos = hotcheck.tail_load_positions(hotcheck.listing(build.build()))
+    assert len(pos) >= 20 and all(v is not None and v <= hotcheck.TAIL_LOAD_LIMIT for v in pos.values()), pos
