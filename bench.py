@@ -5,22 +5,28 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 One "step" = one `VecEnv.step` of the hot path over this rank's 65 536 environments (medium scenario, base physics,
-fp32; BASELINE.json configs[1]): ONE launch of the fused HIP kernel, auto-resets included.  Actions come from a
-pre-generated tape already resident in HBM; launches are issued back to back from C (`hlx_rollout`), one per step, as a
-policy-free rollout would.  Environments shard over ranks with no collective in the step (weak scaling).
+fp32; BASELINE.json configs[1]): ONE launch of the fused HIP kernel, auto-resets included, IN THE FORM THE DROP-IN
+ISSUES (`HlynrVecEnv.step_torch` -> `hlx_step` with terminal observations, every info plane and the done list: SB3
+bootstraps from `infos[i]['terminal_observation']`, the reference's trainers read the info keys).  Actions come from a
+pre-generated tape already resident in HBM; launches are issued back to back from C (`hlx_rollout` with
+`hlx_set_rollout_outputs`), one per step, as a policy-free rollout would.  Environments shard over ranks with no
+collective in the step (weak scaling).
 
 STEADY STATE.  Right after reset all episodes are in lock-step and every wave takes the same branches; a training run
 never sees that phase again.  Before anything is timed the episodes are therefore desynchronised with a fused rollout
 of `--desync` steps (default 4096, ~30 ms; independent of --warmup): per-launch time then no longer depends on K.
 
 Prints ONE JSON line on rank 0.  `value` = env-steps/s of the whole job (all ranks, max-over-ranks wall time around the
-K timed steps).  `roofline` = algorithmic bytes of one launch / mean launch duration, from HIP events recorded on the
-launch stream around the K back-to-back launches (dependent launches issued ahead of the GPU: the train has no gaps).
-`hlx_rollout` has no terminal-observation output (as in round 1), so its launches observe every environment once;
-`roofline.with_terminal_observations` times the same launches with that output requested.
-`selfcheck` = four 64-environment slabs of this rank's batch replayed from reset through every step of the run -- by
-the CPU oracle, fed the Philox draws the kernel consumed -- and compared with the timed rollout's own outputs and final
-state (non-zero exit status on a mismatch).  `cpu_baseline` = the CPU oracle timed on this host (rank 0, N = 1 only).
+K timed steps, barrier + synchronize on both sides).  `roofline` = algorithmic bytes of one launch / launch duration:
+the duration is the MEDIAN of R = max(5, ceil(400 / K)) back-to-back windows of K launches each, bracketed by HIP events
+recorded on the launch stream (`window_us` lists them all), behind 2000 launches of the same form issued with no host
+synchronisation in between -- a 20-launch window cannot absorb one hiccup, a median of twenty can.  The same
+measurement is repeated for the other forms of the same kernel: `roofline.single_pass` (no optional output: finished
+environments respawn before ONE observation pass) and `roofline.terminal_obs_only`.
+`selfcheck` = four 64-environment slabs of this rank's batch replayed from reset through every step up to the end of
+the timed region -- by the CPU oracle, fed the Philox draws the kernel consumed -- and compared with the timed rollout's
+own outputs and state (non-zero exit status on a mismatch).  `cpu_baseline` = the CPU oracle timed on this host (rank 0,
+N = 1 only).
 
 Other BASELINE.json workloads, not the headline:  --config 4  hard scenario, policy in the loop + gradient all-reduce;
                                                    --config 5  volley K=3 + HRL controller + resident LSTM state.
@@ -38,7 +44,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 65536
-BYTES_PER_ENV_STEP = {"base": 508, "v2dr": 604}     # SURVEY.md 8(d) algorithmic bytes per env-step
+BYTES_PER_ENV_STEP = {"base": 508, "v2dr": 604}     # SURVEY.md 8(d) algorithmic bytes per env-step: state words read once + written
+                                                    # once, I/O words once, info{distance, min_distance} included
+# ... per FORM of the step (roofline accounting):
+#   contract      what HlynrVecEnv.step_torch issues: + info planes fuel 4, fuel_used 4 r + 4 w, flags 1, missiles 1,
+#                 interceptor_pos 12, missile_pos 12, steps 4 = + 42 B.  (Terminal observation, episode return / length and
+#                 the done list are written for finished environments only, ~0.2 B per env-step: not counted.)
+#   single_pass,  no info plane at all: the 8 B of info{distance, min_distance} are not stored, so they are not counted
+#   terminal_obs_only
+FORM_BYTES_DELTA = {"contract": 42, "single_pass": -8, "terminal_obs_only": -8}
+PREROLL = 2000                                      # launches of the same form ahead of every measurement, no host sync behind them
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # The reference's own Python step cannot travel to the GPU box; its numbers were taken in the build container
 # (8 host cores, numpy 2.2.6) and are carried as labelled constants.
@@ -69,9 +84,25 @@ def launch_ranks(argv, n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    # poll: the first rank that fails takes its siblings down (they would otherwise sit in the rendezvous / a barrier
+    # until the process-group timeout); nothing is ever re-exec'd
+    rc, live = 0, list(procs)
+    while live and rc == 0:
+        for p in list(live):
+            code = p.poll()
+            if code is not None:
+                live.remove(p)
+                if code != 0:
+                    rc = abs(code) or 1
+        if live and rc == 0:
+            time.sleep(0.05)
+    for p in live:
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
     return rc
 
 
@@ -140,6 +171,7 @@ class SelfCheck:
         self.flag_bad = 0
         self.obs_bad = 0
         self.obs_max = 0.0
+        self.fuel_used_max = 0.0
         self.last = None
 
     def reset(self):
@@ -167,19 +199,22 @@ class SelfCheck:
             og = np.where(done[:, None], info["terminal_observation"].cpu().numpy(), obs.cpu().numpy())
             oo = np.where(done[:, None], ora.terminal_obs, out["obs"])
             eo = np.max(np.abs(og - oo), axis=1)
-            # a Bernoulli detection decided differently at a float32 boundary moves the Kalman track of that env until
-            # its episode ends (observation only; state, reward and flags are unaffected): counted, not averaged away
+            # a detection decided differently from the oracle would move the Kalman track of that env until its episode ends:
+            # tests/ require that it never happens, and so does this check (counted separately so that the line says which)
             self.obs_bad += int((eo > 1e-3).sum())
-            self.obs_max = max(self.obs_max, float(eo[eo <= 1e-3].max(initial=0.0)))
+            self.obs_max = max(self.obs_max, float(eo.max(initial=0.0)))
+            fu = info["fuel_used"].cpu().numpy().astype(np.float64)
+            self.fuel_used_max = max(self.fuel_used_max, float(np.max(np.abs(fu - out["fuel_used"]) / np.maximum(1.0, np.abs(out["fuel_used"])))))
             self.last.append((obs.clone(), rew.clone(), term.clone(), trunc.clone()))
         self.steps += 1
 
-    def finish(self, big_env, big_last):
-        """big_last = (obs, reward, terminated, truncated) of the big batch's LAST step.  Returns the report dict."""
+    def finish(self, big_state, big_last):
+        """big_state = the big batch's exported state, big_last = its (obs, reward, terminated, truncated), both taken right
+        behind the last step the slabs have replayed.  Returns the report dict."""
         import torch
         identical = True
         state_max = 0.0
-        st_big = np.frombuffer(big_env.get_state(), dtype=np.dtype(type(big_env.get_state()[0])))
+        st_big = np.frombuffer(big_state, dtype=np.dtype(type(big_state[0])))
         for env, ora, s, last in zip(self.envs, self.oras, self.starts, self.last):
             sl = slice(s, s + self.SLAB)
             for x, y in zip(big_last, last):
@@ -194,13 +229,14 @@ class SelfCheck:
         for env in self.envs:
             env.close()
         n = len(self.starts) * self.SLAB
-        # Gate on what the step DEFINES exactly: flags, reward, distance, integrated state, and the big batch == its slabs.
-        # Observation entries are pure outputs of fast float32 formulas, some ill-conditioned by construction (time to
-        # intercept ~ range / closing as closing -> 0): their worst deviation is reported, and gated only at 1e-3.
-        ok = identical and self.flag_bad == 0 and self.rew_max <= 1e-5 and self.dist_max <= 1e-5 and state_max <= 2e-5 and \
-            self.obs_max <= 1e-3 and self.obs_bad <= max(4, n * self.steps // 20000)
+        # Gates: what the step DEFINES exactly (flags, reward, distance, fuel_used, integrated state, big batch == slabs) at
+        # BASELINE.json's 1e-5; observation entries (pure outputs of fast float32 formulas) at the tests' bound, 2e-5
+        # absolute over ALL rows (observed: <= 4e-6); no environment may leave the oracle's detection history.
+        ok = identical and self.flag_bad == 0 and self.rew_max <= 1e-5 and self.dist_max <= 1e-5 and state_max <= 1e-5 and \
+            self.fuel_used_max <= 1e-5 and self.obs_max <= 2e-5 and self.obs_bad == 0
         return {"ok": bool(ok), "envs": n, "global_env_slabs": self.starts, "steps": self.steps, "env_steps": n * self.steps,
                 "batch_equals_slabs_bit_for_bit": bool(identical), "reward_max_rel": self.rew_max, "distance_max_rel": self.dist_max,
+                "fuel_used_max_rel": self.fuel_used_max,
                 "flag_mismatches": self.flag_bad, "obs_max_abs": self.obs_max, "obs_env_steps_with_diverged_detection": self.obs_bad,
                 "state_max_rel": state_max, "against": "oracle/hlx_oracle.c fed the exported Philox draws (hlx_fill_noise)"}
 
@@ -243,9 +279,11 @@ def main():
                          "all-reduce (configs[3]), 5 = volley + HRL controller + LSTM state (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-selfcheck", action="store_true")
-    ap.add_argument("--no-terminal-obs-point", action="store_true",
-                    help="skip the second timing of the same launches with terminal observations requested (profiling runs: keeps "
-                         "the per-kernel averages of rocprofv3 about one form of the step only)")
+    ap.add_argument("--forms", default="contract,single_pass,terminal_obs_only",
+                    help="which forms of the step the event-clocked windows measure (comma separated; the first one is the "
+                         "headline's and must be `contract` unless this is a profiling run that wants one form's launches only)")
+    ap.add_argument("--preroll", type=int, default=PREROLL,
+                    help="launches of the measured form issued ahead of every measurement, with no host synchronisation behind them")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the barrier / max(time); gloo + --single-device rehearses the multi-rank "
                          "path on a one-GPU box")
@@ -263,6 +301,10 @@ def main():
     args = ap.parse_args()
     if args.config == 3:
         args.physics = "v2dr"
+    forms = [f for f in args.forms.split(",") if f]
+    for f in forms:
+        if f not in FORM_BYTES_DELTA:
+            raise SystemExit(f"--forms: unknown form {f!r} (known: {sorted(FORM_BYTES_DELTA)})")
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(sys.argv[1:], args.gpus))        # before this process imports torch or touches a GPU
@@ -275,15 +317,19 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if args.rehearse_cpu:
+        if os.environ.get("HLX_BENCH_TEST_FAIL_RANK") == str(rank):     # tests/test_bench_harness.py: a rank that dies before the rendezvous
+            sys.exit(7)
         import torch.distributed as dist
-        from hlynr_intercept_amd.shard import max_over_ranks, shard_range
+        from hlynr_intercept_amd.shard import gather_over_ranks, max_over_ranks, shard_range
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world > 1:
             dist.init_process_group("gloo", rank=rank, world_size=world)
             dist.barrier()
         slowest = max_over_ranks(1.0 + rank, dist if world > 1 else None, None)
+        per_rank = gather_over_ranks(1.0 + rank, dist if world > 1 else None, None)
         if rank == 0:
             print(json.dumps({"metric": "rehearsal (no GPU work)", "value": None, "n_gpus": world, "slowest_rank_fake_time": slowest,
+                              "per_rank_fake_time": per_rank, "dist_world_size": dist.get_world_size() if world > 1 else 1,
                               "shards": [shard_range(args.envs_per_gpu * world, world, r) for r in range(world)]}), flush=True)
         if world > 1:
             dist.barrier()
@@ -312,7 +358,7 @@ def main():
 
     from hlynr_intercept_amd.config import resolve_config
     from hlynr_intercept_amd.scenarios import scenario_config
-    from hlynr_intercept_amd.shard import max_over_ranks, shard_range, whole_job_throughput
+    from hlynr_intercept_amd.shard import gather_over_ranks, max_over_ranks, shard_range, whole_job_throughput
     from hlynr_intercept_amd.vec_env import HlynrVecEnv
 
     n = args.envs_per_gpu
@@ -323,7 +369,8 @@ def main():
     env = HlynrVecEnv(resolved=rc, num_envs=n, device=local_rank, seed=seed, env_id_offset=offset)
     dev = env.device
     variant = env.kernel_variant      # read now: the handle is gone once the extra points have run
-    K, W, D = args.steps, args.warmup, max(0, args.desync)
+    K, W, D, P = args.steps, args.warmup, max(0, args.desync), max(0, args.preroll)
+    R = max(5, -(-400 // max(1, K)))  # event-clocked windows of K launches each
     gen = torch.Generator(device=dev).manual_seed(rank)      # fixed-seed synthetic action tape, U(-1, 1)
     tape_len = max(min(max(K, W), 2048), 1)
     tape = torch.rand((tape_len, n, 6), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
@@ -331,15 +378,16 @@ def main():
     check = None
     if rank == 0 and not args.no_selfcheck:
         check = SelfCheck(rc, n, seed, offset, local_rank)
+    red_dev = dev if args.backend == "nccl" else None       # gloo reduces a host scalar
 
     def sync_all():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # The launches of a region are issued through the C ABI directly from prepared argument tuples: inside the timed
+    # The launches of a region are issued through the C ABI directly from prepared argument tuples: inside a timed
     # region the host does nothing but call hlx_rollout (one C call per <= tape_len steps), so that a short K is not
-    # dominated by Python (the driver may time as few as 20 steps).
+    # dominated by Python (the driver times as few as 20 steps).
     import ctypes as C
     ring = (torch.zeros((out_slots, n, 26), device=dev), torch.zeros((out_slots, n), device=dev),
             torch.zeros((out_slots, n), dtype=torch.uint8, device=dev), torch.zeros((out_slots, n), dtype=torch.uint8, device=dev))
@@ -355,7 +403,7 @@ def main():
         for a in planned[0]:
             if rollout_c(*a) != 0:
                 raise RuntimeError(env._lib.hlx_last_error().decode())
-        return ring, planned[1]
+        return planned[1]
 
     def run(total, fused=1):
         env.set_rollout_fused(fused)
@@ -363,52 +411,64 @@ def main():
         env.set_rollout_fused(1)
         return ret
 
+    def set_form(form):
+        if form == "contract":                 # what HlynrVecEnv.step_torch / step_async issue
+            env.set_rollout_contract(True, done_list=True)
+        elif form == "terminal_obs_only":
+            env.set_rollout_contract(False)
+            env.set_rollout_terminal_obs(True)
+        else:                                  # single_pass: no optional output
+            env.set_rollout_contract(False)
+
+    def windows(form):
+        """P launches of `form` with no host synchronisation behind them, then R windows of K launches, each bracketed by
+        HIP events on the launch stream (torch events: the launches go to torch's current stream).  Median window."""
+        set_form(form)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(R + 1)]
+        for e in evs:                          # created and recorded once ahead of the measurement (lazy creation is slow)
+            e.record()
+        pre, win = plan(P), plan(K)
+        torch.cuda.synchronize(dev)
+        go(pre)
+        for r in range(R):
+            evs[r].record()
+            go(win)
+        evs[R].record()
+        torch.cuda.synchronize(dev)
+        us = sorted(1e3 * evs[r].elapsed_time(evs[r + 1]) / K for r in range(R))
+        b = (BYTES_PER_ENV_STEP[args.physics] + FORM_BYTES_DELTA[form]) * n
+        med = us[len(us) // 2] if len(us) % 2 else 0.5 * (us[len(us) // 2 - 1] + us[len(us) // 2])
+        return {"kernel_us": med, "window_us": [round(x, 4) for x in us], "windows": R, "launches_per_window": K, "preroll_launches": P,
+                "algorithmic_bytes_per_env_step": b // n, "algorithmic_bytes_per_launch": b,
+                "achieved": b / (med * 1e-6) / 1e9, "frac": b / (med * 1e-6) / 1e9 / HBM_PEAK_GBS}
+
+    # ---------------------------------------------------------------- the timed region (contract form)
     env.reset_torch()
     run(D, fused=64)                  # desynchronise the episodes (bit-identical to D single-step launches)
-    run(W)
+    set_form(forms[0])
+    run(P)                            # the chip is at its working clocks and the host far ahead of it ...
+    run(W)                            # ... then the W untimed warmup steps
     timed = plan(K)
     sync_all()
-    # HIP events recorded on the launch stream bracket the K back-to-back launches of the timed region
-    env.profile(True)
+    env.profile(True)                 # one HIP-event pair on the launch stream from behind the first to behind the last timed launch
     t0 = time.perf_counter()
-    ring, last_slot = go(timed)
+    last_slot = go(timed)
     sync_all()
-    elapsed = time.perf_counter() - t0
-    kern_ms, launches = env.profile_read()
+    elapsed_local = time.perf_counter() - t0
+    region_ms, region_launches = env.profile_read()
     env.profile(False)
-    red_dev = dev if args.backend == "nccl" else None       # gloo reduces a host scalar
-    elapsed = max_over_ranks(elapsed, dist, red_dev)
-    kern_us = 1e3 * kern_ms / max(1, launches)
-    bytes_per_launch = BYTES_PER_ENV_STEP[args.physics] * n
-    achieved = bytes_per_launch / (kern_us * 1e-6) / 1e9 if launches else 0.0
+    elapsed = max_over_ranks(elapsed_local, dist, red_dev)
+    per_rank_ms = [1e3 * x for x in gather_over_ranks(elapsed_local, dist, red_dev)]
     wall_us = 1e6 * elapsed / max(1, K)
+    big_last = big_state = None
+    if check is not None:             # what the slabs and the oracle will be compared with: taken here, right behind the timed region
+        big_last = tuple(x[last_slot].clone() for x in ring)
+        big_state = env.get_state()
 
-    # the same K steps with terminal observations requested (what hlx_step does for an SB3-style caller): finished
-    # environments are then observed twice -- terminal state, then the new episode -- and their waves take a second trip
-    # through the observation code
-    K2, W2 = (0, 0) if args.no_terminal_obs_point else (min(K, 500), min(W, 64) or 1)
-    two_pass_us = None
-    if K2:
-        env.set_rollout_terminal_obs(True)
-        run(W2)
-        sync_all()
-        env.profile(True)
-        ring, last_slot = run(K2)      # (the self-check below compares the outputs of this, the run's very last step)
-        sync_all()
-        tk_ms, tk_launches = env.profile_read()
-        env.profile(False)
-        env.set_rollout_terminal_obs(False)
-        two_pass_us = 1e3 * tk_ms / max(1, tk_launches)
-
-    selfcheck = None
-    if check is not None:     # the slabs and the oracle walk through the same D + W + K steps, then everything is compared
-        check.reset()
-        for total in (D, W, K, W2, K2):       # ... and the terminal-observation rollouts above
-            for lo, hi in tape_schedule(total, tape_len):
-                for j in range(lo, hi):
-                    check.step(tape[j])
-        big_last = tuple(x[last_slot] for x in ring)
-        selfcheck = check.finish(env, big_last)
+    # ---------------------------------------------------------------- event-clocked windows, one set per form
+    measured = {form: windows(form) for form in forms}
+    head = measured[forms[0]]
+    set_form("single_pass")
 
     # SURVEY.md 8(d) caveat: the T-step persistent number beside the one-launch-per-step headline
     fused = None
@@ -427,7 +487,7 @@ def main():
                  "note": "same K steps through hlx_rollout with hlx_set_rollout_fused: state stays in registers for "
                          "steps_per_launch steps, bit-identical results; not the headline (a policy in the loop needs one launch per step)"}
 
-    # config 3 and a batch whose state (2.6 GB) defeats the 256 MB Infinity Cache, same clocking method
+    # config 3 and a batch whose state (2.6 GB) defeats the 256 MB Infinity Cache: contract form, wall clock
     extra = None
     if not args.no_extra_points and world == 1:
         extra = []
@@ -442,6 +502,7 @@ def main():
                 for _ in range(d_x // tape_x.shape[0]):
                     env.rollout_torch(tape_x, out_slots)
                 env.set_rollout_fused(1)
+            env.set_rollout_contract(True, done_list=True)
             env.rollout_torch(tape_x[:max(1, k_x // 4)], out_slots)
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
@@ -449,12 +510,22 @@ def main():
                 env.rollout_torch(tape_x[lo:hi], out_slots)
             torch.cuda.synchronize(dev)
             dt = time.perf_counter() - t0
-            b = BYTES_PER_ENV_STEP[phys]
-            extra.append({"workload": f"medium scenario, {phys} physics, {n_x} envs/GPU", "value": n_x * k_x / dt, "unit": "env-steps/s",
+            b = BYTES_PER_ENV_STEP[phys] + FORM_BYTES_DELTA["contract"]
+            extra.append({"workload": f"medium scenario, {phys} physics, {n_x} envs/GPU", "form": "contract", "value": n_x * k_x / dt, "unit": "env-steps/s",
                           "us_per_step": 1e6 * dt / k_x, "algorithmic_bytes_per_env_step": b, "desync_steps": d_x,
                           "roofline_frac": n_x * k_x * b / dt / 1e9 / HBM_PEAK_GBS})
             env.close()
             del tape_x
+
+    # ---------------------------------------------------------------- self-check (rank 0; every collective is behind us)
+    selfcheck = None
+    if check is not None:     # the slabs and the oracle walk through the same D + P + W + K steps, then everything is compared
+        check.reset()
+        for total in (D, P, W, K):
+            for lo, hi in tape_schedule(total, tape_len):
+                for j in range(lo, hi):
+                    check.step(tape[j])
+        selfcheck = check.finish(big_state, big_last)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -462,6 +533,20 @@ def main():
 
     if rank == 0:
         traffic, traffic_src = measured_traffic(args.physics, n)
+        roof = {"bound": "hbm", "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
+                "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": "hlx_env_kernel<%s, step>" % variant, "form": forms[0],
+                "form_note": "contract = the launch HlynrVecEnv.step_torch issues: terminal observations + every info plane + done list",
+                "kernel_us": head["kernel_us"], "kernel_us_clock": f"median of {R} back-to-back windows of {K} launches (HIP events on the "
+                                                                    f"launch stream) behind {P} launches of the same form, no host sync in between",
+                "window_us": head["window_us"], "algorithmic_bytes_per_env_step": head["algorithmic_bytes_per_env_step"],
+                "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"],
+                "timed_region": {"kernel_us": 1e3 * region_ms / max(1, region_launches), "launches": region_launches,
+                                 "wall_us_per_step": wall_us,
+                                 "note": "the K wall-clock-timed launches themselves: one event pair from behind the first to behind the last"},
+                "frac_from_wall_clock": head["algorithmic_bytes_per_launch"] / (wall_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+        for form in forms[1:]:
+            roof[form] = measured[form]
         line = {
             "metric": "env-steps/sec whole-node, medium scenario, 64k envs/GPU",
             "value": whole_job_throughput(n, K, world, elapsed), "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -469,17 +554,12 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"medium scenario, {args.physics} physics, {n} envs/GPU, fp32 "
                                    f"(BASELINE.json configs[{1 if args.physics == 'base' else 2}])",
-                       "envs_per_gpu": n, "kernel_variant": variant, "launches_per_step": 1,
-                       "phase": f"steady state: episodes desynchronised by {D} fused-rollout steps + {W} warmup steps before the timed region",
+                       "envs_per_gpu": n, "kernel_variant": variant, "launches_per_step": 1, "form": forms[0],
+                       "phase": f"steady state: episodes desynchronised by {D} fused-rollout steps, then {P} + {W} untimed steps of the timed form",
                        "sharding": f"{world} x {n} independent envs, no collective in the step"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "hlx_env_kernel<%s, step>" % variant,
-                         "kernel_us": kern_us, "wall_us_per_step": wall_us, "frac_from_wall_clock": bytes_per_launch / (wall_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "launches_timed": launches,
-                         "with_terminal_observations": None if two_pass_us is None else {
-                             "kernel_us": two_pass_us, "frac": bytes_per_launch / (two_pass_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                             "note": "same launches with hlx_set_rollout_terminal_obs: finished environments observed twice"}},
+            "ranks": {"dist_world_size": dist.get_world_size() if dist is not None else 1, "backend": args.backend if dist is not None else None,
+                      "per_rank_ms": per_rank_ms},
+            "roofline": roof,
             "selfcheck": selfcheck,
             "cpu_baseline": cpu,
             "fused_rollout": fused,

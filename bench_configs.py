@@ -121,7 +121,7 @@ def config4(args, rank, local_rank, world, dist):
     import torch
     from hlynr_intercept_amd.config import resolve_config
     from hlynr_intercept_amd.scenarios import scenario_config
-    from hlynr_intercept_amd.shard import max_over_ranks, shard_range
+    from hlynr_intercept_amd.shard import gather_over_ranks, max_over_ranks, shard_range
     from hlynr_intercept_amd.vec_env import HlynrVecEnv
     from hlynr_intercept_amd.wrappers import VecFrameStack, VecNormalize
 
@@ -180,6 +180,7 @@ def config4(args, rank, local_rank, world, dist):
     torch.cuda.synchronize(dev)
     t_upd = time.perf_counter() - t0
     red = dev if args.backend == "nccl" else None
+    per_rank_ms = [1e3 * x for x in gather_over_ranks(t_roll, dist, red)]
     t_roll, t_upd = max_over_ranks(t_roll, dist, red), max_over_ranks(t_upd, dist, red)
     tot = sections.totals_us()
     T, M = args.rollout_steps, max(1, args.minibatches)
@@ -195,6 +196,8 @@ def config4(args, rank, local_rank, world, dist):
         "shares_us_per_step": {"policy forward + sampling": tot.get("policy", 0.0) / T, "env step + frame stack + normalise": tot.get("env+pipeline", 0.0) / T},
         "update_us_per_minibatch": {"forward + backward": tot.get("update fwd+bwd", 0.0) / M, "gradient all-reduce": tot.get("gradient all-reduce", 0.0) / M,
                                     "optimiser": tot.get("optimiser", 0.0) / M, "wall": 1e6 * t_upd / M},
+        "ranks": {"dist_world_size": dist.get_world_size() if dist is not None else 1, "backend": args.backend if dist is not None else None,
+                  "per_rank_rollout_ms": per_rank_ms},
         "gradient_bucket_bytes": bucket, "parameters": sum(p.numel() for p in params),
         "episodes_finished_in_rollout": int(n_done.item()) if n_done is not None else 0,
         "note": "measurement harness, not a PPO implementation: the loss is a stand-in that yields gradients of the policy's size",
@@ -207,7 +210,7 @@ def config5(args, rank, local_rank, world, dist):
     import torch
     from hlynr_intercept_amd.hrl import HRLController, SEARCH, TERMINAL, TRACK
     from hlynr_intercept_amd.scenarios import scenario_config
-    from hlynr_intercept_amd.shard import max_over_ranks, shard_range
+    from hlynr_intercept_amd.shard import gather_over_ranks, max_over_ranks, shard_range
     from hlynr_intercept_amd.vec_env import HlynrVecEnv
     from hlynr_intercept_amd.wrappers import VecFrameStack
 
@@ -260,7 +263,9 @@ def config5(args, rank, local_rank, world, dist):
     t0 = time.perf_counter()
     loop(T, sections)
     torch.cuda.synchronize(dev)
-    elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev if args.backend == "nccl" else None)
+    local = time.perf_counter() - t0
+    per_rank_ms = [1e3 * x for x in gather_over_ranks(local, dist, dev if args.backend == "nccl" else None)]
+    elapsed = max_over_ranks(local, dist, dev if args.backend == "nccl" else None)
     tot = sections.totals_us()
     state_bytes = sum(x.numel() * x.element_size() for x in ctl.lstm_state) if ctl.lstm_state else 0
     line = {
@@ -272,6 +277,8 @@ def config5(args, rank, local_rank, world, dist):
                                f"selector, decision interval 100), three recurrent specialists (actor + critic LSTM 104->256, torch, random weights)",
                    "kernel_variant": base.kernel_variant},
         "shares_us_per_step": {k: v / T for k, v in tot.items()},
+        "ranks": {"dist_world_size": dist.get_world_size() if dist is not None else 1, "backend": args.backend if dist is not None else None,
+                  "per_rank_ms": per_rank_ms},
         "lstm_state_resident_bytes": state_bytes, "lstm_state_bytes_per_env": state_bytes // max(1, n),
         "options_now": torch.bincount(ctl.option.to(torch.int64), minlength=3).tolist(),
     }

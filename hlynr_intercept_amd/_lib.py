@@ -50,7 +50,7 @@ class HlxInfoSoa(C.Structure):
     _fields_ = [("distance", C.c_void_p), ("min_distance", C.c_void_p), ("fuel", C.c_void_p), ("flags", C.c_void_p),
                 ("episode_return", C.c_void_p), ("episode_length", C.c_void_p), ("missiles", C.c_void_p),
                 ("interceptor_pos", C.c_void_p), ("missile_pos", C.c_void_p), ("steps", C.c_void_p),
-                ("missile_min_distances", C.c_void_p), ("radar_debug", C.c_void_p)]
+                ("missile_min_distances", C.c_void_p), ("radar_debug", C.c_void_p), ("fuel_used", C.c_void_p)]
 
 
 class HlxEnvState(C.Structure):
@@ -98,6 +98,10 @@ SYMBOLS = {
     "hlx_set_state": (C.c_int, [_P, _P]),
     "hlx_set_rollout_fused": (C.c_int, [_P, i32]),
     "hlx_set_rollout_terminal_obs": (C.c_int, [_P, _P]),
+    "hlx_set_rollout_outputs": (C.c_int, [_P, _P, _P, C.POINTER(HlxInfoSoa)]),
+    "hlx_set_done_counter": (C.c_int, [_P, _P]),
+    "hlx_set_reset_epoch": (C.c_int, [_P, u32]),
+    "hlx_get_reset_epoch": (u32, [_P]),
     "hlx_set_seed": (C.c_int, [_P, u64]),
     "hlx_selftest_math": (C.c_int, [i32, _P, f32, _P, i64, _P]),
     "hlx_set_load_schedule": (C.c_int, [_P, i32]),
@@ -168,7 +172,16 @@ def _load(build_if_missing: bool):
         except Exception as exc:  # pragma: no cover
             if not os.path.exists(path):
                 raise RuntimeError(f"libhlx.so is missing and could not be built: {exc}") from exc
-            raise RuntimeError(f"libhlx.so is out of date with csrc/ and could not be rebuilt: {exc}") from exc
+            # An existing library whose sources have moved on: refuse it where a rebuild was POSSIBLE and failed (a compile
+            # error must not be papered over with stale code); use it, loudly, where this installation cannot rebuild at all
+            # (no hipcc, or a read-only package directory: an installed copy next to sources it was not built from).
+            import shutil
+            import warnings
+            can_rebuild = (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")) and os.access(os.path.dirname(path), os.W_OK)
+            if can_rebuild:
+                raise RuntimeError(f"libhlx.so is out of date with csrc/ and could not be rebuilt: {exc}") from exc
+            warnings.warn(f"libhlx.so differs from the sources in csrc/ and cannot be rebuilt here ({exc}); using the existing library",
+                          RuntimeWarning, stacklevel=3)
     if not os.path.exists(path):
         raise RuntimeError(f"HIP library not found at {path}: build it with `python -m hlynr_intercept_amd.build`")
     # One HIP runtime per process.  PyTorch-ROCm wheels carry their own libamdhip64 / libhsa-runtime64; libhlx.so names the

@@ -48,6 +48,13 @@ namespace {
 // rare branches: laid out of line so that the hot path is one contiguous instruction stream (the step is ~2000 instructions
 // executed once per wave and launch: instruction fetch is cold, and every taken branch over a cold block breaks the prefetch)
 #define RARE(x) __builtin_expect(!!(x), 0)
+// The optional info planes: in line (round 3).  Until round 2 the benchmark's launches asked for none and the block sat out of
+// line behind RARE(); the headline is now the launch the drop-in really issues (hlx_step with every info plane), and there the
+// block runs in every wave -- out of line it would cost each of them two taken far branches.  -DHLX_INFO_RARE=1: the old layout (A/B).
+#ifndef HLX_INFO_RARE
+#define HLX_INFO_RARE 0
+#endif
+#define INFO_WANTED(x) (HLX_INFO_RARE ? RARE(x) : (x))
 
 // Diagnostic build only (-DHLX_STAMPS): lane 0 of every wave records s_memtime at a few program points into
 // a.stamps[block][16].  No stamp executes in the product build, and no output is ever computed from one.
@@ -360,6 +367,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             WAVE_LDS_SYNC();   // one wave per workgroup: orders the LDS writes before the per-lane lookups below
         }
         done_idx_out = HOT(opt.done_idx);
+        // info['fuel_used'] (environment.py:886) accumulates in the CALLER's plane (hlx.h): last step's value is fetched here, as
+        // soon as the hot words can be read, and is first needed in the info block a whole physics section later
+        float fuel_used_prev = 0.f;
+        if (MODE == 0 && INFO_WANTED(slots & (1u << 20)) && HOT(opt.info.fuel_used)) fuel_used_prev = HOT(opt.info.fuel_used)[ic];
         if (live) {   // ============================== per-environment work, live lanes only ==============================
         STAMP(2);   // Philox block done (loads still in flight)
         V3 ipos = v3(g_ipos.x, g_ipos.y, g_ipos.z), ivel = v3(g_ivel.x, g_ivel.y, g_ivel.z);
@@ -403,6 +414,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             }
         }
 
+        float fuel_step = 0.f;   // this step's fuel consumption (environment.py:884)
         float reward = 0.f, distance = 0.f, range_c = 0.f;   // range_c: ||missile - interceptor|| of the state the observation will see
         bool terminated = false, truncated = false, intercepted = false, hit_target = false, fuze = false,
              clamped = false;
@@ -448,6 +460,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             }
             float fc = (divc(snorm3(thr), 1.0 / 500.0) * 0.1f) * HOT(c.dt);              // :883-884
             fuel = fuel - fc;
+            fuel_step = fc;
             if (RARE(fuel <= 0.f)) { fuel = 0.f; thr = v3(0.f, 0.f, 0.f); thrust_act = thr; } // :888-892
             const V3 tacc = divc(thr, 1.0 / 500.0);                                 // :896
             float rho = 1.225f, sos = 343.f;
@@ -735,10 +748,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             reward_out[i] = reward;
             term_out[i] = terminated ? 1 : 0;
             trunc_out[i] = truncated ? 1 : 0;
-            if (RARE(slots & (1u << 20))) {   // some hlx_info_soa plane is wanted (one SGPR test instead of nine pointer fetches)
+            if (INFO_WANTED(slots & (1u << 20))) {   // some hlx_info_soa plane is wanted (one SGPR test instead of nine pointer fetches)
             if (HOT(opt.info.distance)) HOT(opt.info.distance)[i] = distance;
             if (HOT(opt.info.min_distance)) HOT(opt.info.min_distance)[i] = min_distance;
             if (HOT(opt.info.fuel)) HOT(opt.info.fuel)[i] = fuel;
+            if (HOT(opt.info.fuel_used))    // :886 `self.total_fuel_used += fuel_consumed` (float32; 0 at reset, :566)
+                HOT(opt.info.fuel_used)[i] = (steps == 1) ? fuel_step : fuel_used_prev + fuel_step;
             if (HOT(opt.info.interceptor_pos)) {                                  // :836-838 (post-step, pre-respawn values)
                 float* ip = HOT(opt.info.interceptor_pos) + i;
                 ip[0] = ipos.x; ip[(size_t)n] = ipos.y; ip[2 * (size_t)n] = ipos.z;
@@ -1201,8 +1216,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                             const V3 xp = to_v3(kxp), xv = to_v3(kxv);
                             kxp = to_d3(v3(xp.x + HOT(c.dt) * xv.x, xp.y + HOT(c.dt) * xv.y, xp.z + HOT(c.dt) * xv.z));
                         }
-                        const float a_pp = p_pp + HOT(c.dt) * p_vp, a_pv = p_pv + HOT(c.dt) * p_vv;
-                        const float n_pp = a_pp + a_pv * HOT(c.dt), n_vp = p_vp + p_vv * HOT(c.dt);
+                        // `F @ P @ F.T` = two OpenBLAS sgemm calls: every element is ONE fused multiply-add chain over k (pinned
+                        // against numpy in oracle/hlx_oracle.c kf_predict); with F = [I dt I; 0 I] that is fmaf(dt, b, a).
+                        // (The state's `F @ x` above is sgemv / dgemv, which does not fuse.)
+                        const float a_pp = __builtin_fmaf(HOT(c.dt), p_vp, p_pp), a_pv = __builtin_fmaf(HOT(c.dt), p_vv, p_pv);
+                        const float n_pp = __builtin_fmaf(a_pv, HOT(c.dt), a_pp), n_vp = __builtin_fmaf(p_vv, HOT(c.dt), p_vp);
                         p_pp = n_pp + HOT(c.q11); p_pv = a_pv + HOT(c.q12); p_vp = n_vp + HOT(c.q12); p_vv = p_vv + HOT(c.q22);
                     }
                     have_track = kf_init;

@@ -16,6 +16,15 @@ draws, evaluated in wave-uniform control flow); a plain copy whose chain leads b
 a live-range split, possibly copied back later), a scratch reload or an AGPR read-back = the hazard, made under whatever
 EXEC mask was current.  Registers are recycled (a baked instantiation may never read one of its hot words and reuse the
 register for something else), so the classification is per read, not per register.
+Round 3 (advisor finding: a hot word rematerialised through v_cndmask / a DPP move / v_or / v_perm passed as "computed"):
+  * a hot word is identified by its LOAD, not by the opcode alone: `global_load_dword vX, vLANE, s[P:P+1]` (offset 0 or 256)
+    from the SGPR pair the kernel's first such load uses -- the parameter-block pointer; other single-dword loads (the
+    info['fuel_used'] accumulator) are ordinary values;
+  * while a register holds a hot word, v_readlane_b32 is the ONLY instruction that may read it: any other reader (a copy,
+    a select, a DPP / permute move, a spill store, an AGPR write) is reported, whatever it feeds -- a lane-local use of a
+    hot word has no meaning in this kernel, so every such instruction is the beginning of a rematerialisation;
+  * "computed" cross-lane reads are legitimate only for the wave-cooperative respawn draws (RS_ITEMS x 4 = 44) and the
+    compaction bookkeeping: at most COMPUTED_READLANE_LIMIT per instantiation (measured: 19-52).
 Usage: python -m hlynr_intercept_amd.hotcheck [libhlx.so | listing.s]; exit code 1 on a spill reload.
 hlynr_intercept_amd/build.py runs the same check after every build (`verify`)."""
 import collections
@@ -68,12 +77,17 @@ def listing(path=None):
 
 
 def regs(operand):
-    """'v12' -> [12]; 'v[4:7]' -> [4, 5, 6, 7]."""
+    """'v12' -> [12]; 'v[4:7]' -> [4, 5, 6, 7]; source modifiers ('-v3', '|v3|') are looked through."""
+    operand = operand.strip("-|")
     m = re.fullmatch(r"v(\d+)", operand)
     if m:
         return [int(m.group(1))]
     m = re.fullmatch(r"v\[(\d+):(\d+)\]", operand)
     return list(range(int(m.group(1)), int(m.group(2)) + 1)) if m else []
+
+
+COMPUTED_READLANE_LIMIT = 64     # cross-lane reads of computed values per instantiation (respawn draws 44 + bookkeeping; measured 19-52)
+_STORES = ("global_store", "buffer_store", "scratch_store", "flat_store", "ds_write", "global_atomic", "buffer_atomic", "flat_atomic", "ds_add")
 
 
 def check(text):
@@ -91,18 +105,30 @@ def check(text):
         readlane_src, writelane_dst = set(), set()
         reads = collections.defaultdict(list)           # reg -> [positions of v_readlane]
         writes = collections.defaultdict(list)          # reg -> [(position, opcode, source operands)]
+        other_readers = []                              # (position, opcode, [source VGPRs]) of everything that is not a v_readlane
+        hot_base = None                                 # SGPR pair of the parameter-block pointer: the first `global_load_dword v, v, s[a:b]`
         for pos, t in enumerate(x.strip() for x in lines[i + 1:end]):
             if not t or t.startswith((".", ";")):
                 continue
             parts = t.replace(",", " ").split()
             op = parts[0]
+            if op == "global_load_dword" and len(parts) > 3 and re.fullmatch(r"s\[\d+:\d+\]", parts[3]):
+                if hot_base is None:
+                    hot_base = parts[3]
+                if parts[3] == hot_base and (len(parts) == 4 or parts[4] in ("offset:256",)):
+                    op = "HOT_LOAD"
+            if op != "v_readlane_b32" and len(parts) > 1 and (op.startswith(("v_", "ds_", "scratch_", "global_", "buffer_", "flat_"))):
+                src_ops = parts[1:] if op.startswith(_STORES) or op.startswith("v_cmp") else parts[2:]
+                srcs = [r for o in src_ops for r in regs(o)]
+                if srcs:
+                    other_readers.append((pos, parts[0], srcs))
             if op == "v_readlane_b32":
                 for r in regs(parts[2]):
                     readlane_src.add(r)
                     reads[r].append(pos)
             if op == "v_writelane_b32":
                 writelane_dst.update(regs(parts[1]))
-            if op.startswith(("v_", "global_load", "buffer_load", "scratch_load", "ds_read", "ds_bpermute", "flat_load")) and \
+            if op.startswith(("v_", "global_load", "buffer_load", "scratch_load", "ds_read", "ds_bpermute", "flat_load", "HOT_LOAD")) and \
                     not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")) and len(parts) > 1:
                 for r in regs(parts[1]):
                     writes[r].append((pos, op, parts[2:]))
@@ -117,7 +143,7 @@ def check(text):
             if w is None:
                 return "nothing"
             wpos, op, src = w
-            if op == "global_load_dword":
+            if op == "HOT_LOAD":
                 return "hot"
             if op.startswith("scratch_load") or op.startswith("v_accvgpr_read"):
                 return "reload"
@@ -136,13 +162,25 @@ def check(text):
         #   hot        -- still the value the parameter-block load put there: all 64 lanes valid, fine;
         #   computed   -- an ordinary value (the wave-cooperative respawn draws, evaluated in wave-uniform control flow);
         #   copy / reload of a hot word -- made under whatever EXEC mask was current: the hazard this check exists for.
+        computed_reads = 0
         for r in sorted(readlane_src - writelane_dst):
             kinds = collections.Counter(origin(r, rp) for rp in reads[r])
+            computed_reads += kinds.get("computed", 0)
             bad = {k: v for k, v in kinds.items() if k in ("copy-of-hot", "reload", "nothing")}
             if bad:
                 fail.append((name, f"v{r}", {"v_readlane of a " + k: v for k, v in bad.items()}))
             else:
                 info.append((name, f"v{r}", dict(kinds)))
+        # a register that holds a hot word may be read by v_readlane_b32 and by nothing else
+        leaks = collections.Counter()
+        for pos, opname, srcs in other_readers:
+            for r in srcs:
+                if r not in writelane_dst and origin(r, pos) == "hot":
+                    leaks[(f"v{r}", opname)] += 1
+        for (reg, opname), cnt in sorted(leaks.items()):
+            fail.append((name, reg, {"hot word read by " + opname + " (only v_readlane_b32 may)": cnt}))
+        if computed_reads > COMPUTED_READLANE_LIMIT:
+            fail.append((name, "*", {f"v_readlane of computed values: {computed_reads} > {COMPUTED_READLANE_LIMIT}": computed_reads}))
     return len(starts), fail, info
 
 

@@ -34,6 +34,18 @@ def max_over_ranks(value: float, dist=None, device=None) -> float:
     return float(t.item())
 
 
+def gather_over_ranks(value: float, dist=None, device=None):
+    """Every rank's value, in rank order (a SCALE record can then show that N ranks really ran and how far apart they were)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    import torch
+
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
+
+
 def whole_job_throughput(envs_per_rank: int, steps: int, world_size: int, elapsed_max: float) -> float:
     """env-steps/s of the whole job: all ranks' work over the slowest rank's time."""
     return float(envs_per_rank) * steps * world_size / elapsed_max

@@ -108,9 +108,8 @@ class LazyInfos(Sequence):
             "missiles_intercepted": int(h["missiles"][i]) & 15, "missiles_remaining": int(h["missiles"][i]) >> 4,
             # environment.py:836-841 (read by train_hrl_pretrain.py:180-198, inference.py:535-560)
             "interceptor_pos": h["interceptor_pos"][:, i].copy(), "missile_pos": h["missile_pos"][:, i].copy(),
-            # fuel_used: the reference accumulates `total_fuel_used` step by step (environment.py:886); here it is 100 - fuel,
-            # equal up to float32 rounding and the overshoot of the step that empties the tank
-            "steps": int(h["steps"][i]), "fuel_used": float(100.0 - h["fuel"][i]),
+            # fuel_used: the reference's `total_fuel_used` (environment.py:886), accumulated step by step in float32 by the kernel
+            "steps": int(h["steps"][i]), "fuel_used": float(h["fuel_used"][i]),
             # environment.py:840 <- core.py:536,584: the configured quality whenever a delayed onboard sample exists
             "radar_quality": float(h["radar_quality"]) if flags & 128 else 0.0,
             # environment.py:848: per-missile closest approach in volley mode, [distance] otherwise
@@ -196,20 +195,38 @@ class HlynrVecEnv(_SB3VecEnv):
         self.observation_space = _box(-2.0, 1.0, (_lib.OBS_DIM,))     # environment.py:192-194
         self.action_space = _box(-1.0, 1.0, (_lib.ACT_DIM,))          # environment.py:195-197
         self._lib = _lib.load()
+        self._seed, self._env_id_offset, self._radar_debug = int(seed), int(env_id_offset), bool(radar_debug)
+        self._h = C.c_void_p()
+        self._closed = True
+        self._config_volley = (bool(self.rc.volley_mode), int(self.rc.volley_size))     # what `self.config` says (environment.py:42-43)
+        self._open()
+        self._pending = None
+        self._t_start = time.time()
+        self._noise = None
+        self.training_step_count = 0
+        if _SB3VecEnv is not object:   # SB3's own bookkeeping (reset_infos, _seeds, _options, render_mode)
+            _SB3VecEnv.__init__(self, self.num_envs, self.observation_space, self.action_space)
+
+    def _open(self):
+        """Create the handle for `self.rc` and the I/O buffers it writes (also used by `reset(options=...)` when the
+        volley settings change: volley mode is a code-generation flag, so the other mode is another handle)."""
+        torch, radar_debug = self._torch, self._radar_debug
         self._cfg = _lib.make_hlx_config(self.rc)
         if radar_debug:
             self._cfg.flags |= _lib.F_RADAR_DEBUG      # generic kernel variant: the specialised ones carry no debug export
         self._h = C.c_void_p()
-        _lib.check(self._lib.hlx_create(C.byref(self._cfg), self.num_envs, self.device_index, int(seed),
-                                        int(env_id_offset), C.byref(self._h)))
+        _lib.check(self._lib.hlx_create(C.byref(self._cfg), self.num_envs, self.device_index, self._seed,
+                                        self._env_id_offset, C.byref(self._h)))
+        self._closed = False
+        self._ro_key = None
         n, dev = self.num_envs, self.device
         self.obs = torch.zeros((n, _lib.OBS_DIM), dtype=torch.float32, device=dev)
         # Per-step scalar outputs live in ONE device slab (256-byte aligned typed views), so that the numpy path brings
         # them to the host with a single copy instead of a dozen.
         f32, u8, i32 = torch.float32, torch.uint8, torch.int32
         _NP_DTYPES.update({f32: np.float32, u8: np.uint8, i32: np.int32})
-        spec = [("reward", f32, (n,)), ("terminated", u8, (n,)), ("truncated", u8, (n,)), ("n_done", i32, (1,)),
-                ("distance", f32, (n,)), ("min_distance", f32, (n,)), ("fuel", f32, (n,)), ("flags", u8, (n,)),
+        spec = [("reward", f32, (n,)), ("terminated", u8, (n,)), ("truncated", u8, (n,)), ("n_done", i32, (2,)),
+                ("distance", f32, (n,)), ("min_distance", f32, (n,)), ("fuel", f32, (n,)), ("fuel_used", f32, (n,)), ("flags", u8, (n,)),
                 ("missiles", u8, (n,)), ("interceptor_pos", f32, (3, n)), ("missile_pos", f32, (3, n)), ("steps", i32, (n,))]
         if self.rc.volley_mode:
             spec.append(("missile_min_distances", f32, (_lib.MAX_VOLLEY, n)))
@@ -222,14 +239,18 @@ class HlynrVecEnv(_SB3VecEnv):
             off += (nbytes + 255) // 256 * 256
         self._slab = torch.zeros(off, dtype=u8, device=dev)
         v = {name: self._slab[o:o + nb].view(dt).view(shape) for name, (o, nb, dt, shape) in self._slab_layout.items()}
-        self.reward, self.terminated, self.truncated, self.n_done = v["reward"], v["terminated"], v["truncated"], v["n_done"]
+        self.reward, self.terminated, self.truncated = v["reward"], v["terminated"], v["truncated"]
+        # the kernel counts finished environments straight into the slab (element `vec-step clock & 1`): no copy per step
+        self._n_done2 = v["n_done"]
+        self.n_done = self._n_done2[0:1]
+        _lib.check(self._lib.hlx_set_done_counter(self._h, self._n_done2.data_ptr()))
         self.terminal_obs = torch.zeros((n, _lib.OBS_DIM), dtype=torch.float32, device=dev)
         self.done_idx = torch.zeros(n, dtype=torch.int32, device=dev)
         self.info = dict(distance=v["distance"], min_distance=v["min_distance"], fuel=v["fuel"], flags=v["flags"],
                          episode_return=torch.zeros(n, device=dev),
                          episode_length=torch.zeros(n, dtype=torch.int32, device=dev),
                          missiles=v["missiles"], interceptor_pos=v["interceptor_pos"], missile_pos=v["missile_pos"],
-                         steps=v["steps"])
+                         steps=v["steps"], fuel_used=v["fuel_used"])
         if self.rc.volley_mode:
             self.info["missile_min_distances"] = v["missile_min_distances"]
         if radar_debug:
@@ -238,16 +259,10 @@ class HlynrVecEnv(_SB3VecEnv):
                                            ("distance", "min_distance", "fuel", "flags", "episode_return",
                                             "episode_length", "missiles", "interceptor_pos", "missile_pos", "steps")),
                                          self.info["missile_min_distances"].data_ptr() if self.rc.volley_mode else None,
-                                         self.info["radar_debug"].data_ptr() if radar_debug else None)
+                                         self.info["radar_debug"].data_ptr() if radar_debug else None,
+                                         self.info["fuel_used"].data_ptr())
         self._actions_dev = torch.zeros((n, _lib.ACT_DIM), dtype=torch.float32, device=dev)
         self._actions_pin = torch.zeros((n, _lib.ACT_DIM), dtype=torch.float32, pin_memory=True)
-        self._pending = None
-        self._t_start = time.time()
-        self._closed = False
-        self._noise = None
-        self.training_step_count = 0
-        if _SB3VecEnv is not object:   # SB3's own bookkeeping (reset_infos, _seeds, _options, render_mode)
-            _SB3VecEnv.__init__(self, self.num_envs, self.observation_space, self.action_space)
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -299,6 +314,8 @@ class HlynrVecEnv(_SB3VecEnv):
             actions = actions.to(device=self.device, dtype=t.float32).contiguous()
         if tuple(actions.shape) != (self.num_envs, _lib.ACT_DIM):
             raise ValueError(f"actions must have shape ({self.num_envs}, {_lib.ACT_DIM}), got {tuple(actions.shape)}")
+        # the count of the step about to be issued lands in element (clock & 1) of the slab's counter pair
+        self.n_done = self._n_done2[(int(self._lib.hlx_vec_steps(self._h)) + 1) & 1:][:1]
         di = self.done_idx.data_ptr() if want_done_list else None
         nd = self.n_done.data_ptr() if want_done_list else None
         _lib.check(self._lib.hlx_step(self._h, actions.data_ptr(), obs_ptr if obs_ptr is not None else self.obs.data_ptr(),
@@ -331,9 +348,33 @@ class HlynrVecEnv(_SB3VecEnv):
         return o, r, te, tr
 
     # ------------------------------------------------------------------ SB3 VecEnv API (numpy at the boundary)
-    def reset(self):
+    def reset(self, seed: Optional[int] = None, options: Optional[Dict[str, Any]] = None):
+        """`gym.Env.reset(seed=None, options=None)` for the whole batch (environment.py:353-366); SB3 calls it bare.
+        `seed` re-keys the counter-based generator (as `VecEnv.seed`); `options` may carry the reference's per-reset
+        override `{'volley_mode': bool, 'volley_size': int}` (environment.py:363-366), which stays in force for later
+        resets, as the reference's attributes do."""
+        if options is not None:
+            self._apply_volley_options(options)
+        if seed is not None:
+            self.seed(seed)
         self._t_start = time.time()
         return self.reset_torch().cpu().numpy()
+
+    def _apply_volley_options(self, options):
+        # environment.py:364-365: options.get(key, config default) -- a key that is absent falls back to the CONFIG's value
+        mode = bool(options.get("volley_mode", self._config_volley[0]))
+        size = int(options.get("volley_size", self._config_volley[1]))
+        if mode == bool(self.rc.volley_mode) and (not mode or size == int(self.rc.volley_size)):
+            return
+        if mode and not 1 <= size <= _lib.MAX_VOLLEY:
+            raise ValueError(f"volley_size must be 1..{_lib.MAX_VOLLEY} (got {size})")
+        import dataclasses
+        step_count, was_set = self.training_step_count, getattr(self, "_step_count_set", False)
+        self.close()
+        self.rc = dataclasses.replace(self.rc, volley_mode=mode, volley_size=size if mode else 1)
+        self._open()                      # every environment of the new handle is un-reset; the caller's reset follows
+        if was_set:
+            self.set_training_step_count(step_count)
 
     def step_async(self, actions):
         if self._pending is not None:
@@ -382,10 +423,10 @@ class HlynrVecEnv(_SB3VecEnv):
         obs_h, rew_h = obs_t.numpy(), plane("reward")
         term_h, trunc_h = plane("terminated").astype(bool), plane("truncated").astype(bool)
         dones = term_h | trunc_h
-        n_done = int(plane("n_done")[0])
+        n_done = int(plane("n_done")[int(self._lib.hlx_vec_steps(self._h)) & 1])
         host = dict(terminated=term_h, truncated=trunc_h, t_start=self._t_start, radar_quality=self.rc.radar_quality,
                     volley=(bool(self.rc.volley_mode), int(self.rc.volley_size) if self.rc.volley_mode else 1))
-        for k in ("distance", "min_distance", "fuel", "flags", "missiles", "interceptor_pos", "missile_pos", "steps"):
+        for k in ("distance", "min_distance", "fuel", "fuel_used", "flags", "missiles", "interceptor_pos", "missile_pos", "steps"):
             host[k] = plane(k)
         if "missile_min_distances" in self._slab_layout:
             host["missile_min_distances"] = plane("missile_min_distances")
@@ -410,7 +451,8 @@ class HlynrVecEnv(_SB3VecEnv):
         draws from Philox(seed, env_id_offset + i, vec-step clock) from the next launch on; SB3 callers follow with
         `reset()`.  `None` keeps the current key, as `gym.Env.reset(seed=None)` keeps its generator."""
         if seed is not None:
-            _lib.check(self._lib.hlx_set_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF))
+            self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+            _lib.check(self._lib.hlx_set_seed(self._h, self._seed))
         return [seed] * self.num_envs
 
     def set_load_schedule(self, mode: int):
@@ -473,6 +515,7 @@ class HlynrVecEnv(_SB3VecEnv):
     def set_training_step_count(self, step_count: int):
         """environment.py:269-272 - O(1): the schedules are evaluated host-side, values ride as kernel args."""
         self.training_step_count = int(step_count)
+        self._step_count_set = True
         _lib.check(self._lib.hlx_set_global_step(self._h, int(step_count)))
 
     def curriculum(self) -> Dict[str, float]:
@@ -516,6 +559,21 @@ class HlynrVecEnv(_SB3VecEnv):
     def set_rollout_terminal_obs(self, enable: bool):
         """rollout_torch (one launch per step) also fills `self.terminal_obs` for the environments that finish in a step."""
         _lib.check(self._lib.hlx_set_rollout_terminal_obs(self._h, self.terminal_obs.data_ptr() if enable else None))
+
+    def set_rollout_contract(self, enable: bool, done_list: bool = True):
+        """rollout_torch (one launch per step) issues exactly the launches `step_torch` does: terminal observations, every
+        info plane (`self.info`) and, with `done_list`, the compacted list of finished environments (`self.done_idx`, its
+        length in `self.n_done_pair[clock & 1]`)."""
+        if enable:
+            _lib.check(self._lib.hlx_set_rollout_outputs(self._h, self.terminal_obs.data_ptr(),
+                                                         self.done_idx.data_ptr() if done_list else None, C.byref(self._info_soa)))
+        else:
+            _lib.check(self._lib.hlx_set_rollout_outputs(self._h, None, None, None))
+
+    @property
+    def n_done_pair(self):
+        """int32[2] on the device: element (vec-step clock & 1) = number of environments that finished in the latest step."""
+        return self._n_done2
 
     def set_rollout_fused(self, steps_per_launch: int):
         """1 = one launch per step (default); k > 1 = rollout_torch keeps the state on-chip for k steps per launch."""

@@ -221,11 +221,17 @@ static void kf_predict(orc_state *s, double dt) { /* core.py:80-89 */
     double dtf = F(dt);
     for (int i = 0; i < 3; ++i) s->kf_x[i] = rr(s->kf_x[i] + rr(dtf * s->kf_x[i + 3], x64), x64);
     float *P = s->kf_P;
+    /* `self.F @ self.P @ self.F.T` are two float32 6x6 matrix products = OpenBLAS sgemm, whose micro-kernel accumulates each
+     * element as ONE fused multiply-add chain over k in ascending order from 0 (measured against numpy 2.2.6 / OpenBLAS 0.3.29
+     * here: 100 % bit match over 3000 random products of every shape the filter forms, dense and block-structured; an unfused
+     * order matches 0-14 %).  With F = [I dt*I; 0 I] a chain has at most two non-zero terms, 1 * a (exact) and dt * b:
+     * element = fmaf(dt, b, a), one rounding.  (`self.F @ self.state` is a matrix-VECTOR product = sgemv / dgemv, which does
+     * not fuse: x + round(dt * v), 100 % over 20 000 draws; the update's products have one non-zero term per element.) */
     double FP[36], FPF[36];
     for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c)
-        FP[r * 6 + c] = (r < 3) ? F((double)P[r * 6 + c] + F(dtf * (double)P[(r + 3) * 6 + c])) : (double)P[r * 6 + c];
+        FP[r * 6 + c] = (r < 3) ? (double)fmaf((float)dtf, P[(r + 3) * 6 + c], P[r * 6 + c]) : (double)P[r * 6 + c];
     for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c)
-        FPF[r * 6 + c] = (c < 3) ? F(FP[r * 6 + c] + F(FP[r * 6 + c + 3] * dtf)) : FP[r * 6 + c];
+        FPF[r * 6 + c] = (c < 3) ? (double)fmaf((float)FP[r * 6 + c + 3], (float)dtf, (float)FP[r * 6 + c]) : FP[r * 6 + c];
     double q = 5.0 * 5.0;                                                         /* core.py:333, :34 */
     double q11 = F(q * pow(dt, 4) / 4.0), q12 = F(q * pow(dt, 3) / 2.0), q22 = F(q * dt * dt); /* :35-42 */
     for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
@@ -951,6 +957,7 @@ void orc_step(const orc_config *c, orc_state *s, const float *action, const doub
     out->terminated = terminated; out->truncated = truncated; out->intercepted = intercepted;
     out->hit_target = hit_target; out->fuze_triggered = fuze; out->clamped = clamped;
     out->distance = (float)distance; out->min_distance = s->min_distance;
+    out->fuel_used = (float)s->total_fuel_used; out->fuel_remaining = s->fuel;   /* :833-834 */
     if (c->volley_mode) {                                                        /* :846-847 */
         out->missiles_intercepted = s->n_intercepted;
         out->missiles_remaining = 0;

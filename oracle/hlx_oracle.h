@@ -99,6 +99,7 @@ typedef struct {
     int32_t terminated, truncated, intercepted, hit_target, fuze_triggered, clamped;
     float distance, min_distance;
     int32_t missiles_intercepted, missiles_remaining;   /* info (:846-847) */
+    float fuel_used, fuel_remaining;                    /* info['fuel_used'] = total_fuel_used (:834, :886), info['fuel_remaining'] (:833) */
 } orc_out;
 
 /* constructor state (T0, drag constants, onboard delay): call once per env before the first reset */

@@ -63,7 +63,7 @@ class OrcOut(C.Structure):
         ("obs", f32 * 26), ("reward", d),
         ("terminated", i32), ("truncated", i32), ("intercepted", i32), ("hit_target", i32),
         ("fuze_triggered", i32), ("clamped", i32), ("distance", f32), ("min_distance", f32),
-        ("missiles_intercepted", i32), ("missiles_remaining", i32),
+        ("missiles_intercepted", i32), ("missiles_remaining", i32), ("fuel_used", f32), ("fuel_remaining", f32),
     ]
 
 
@@ -71,7 +71,7 @@ OUT_DTYPE = np.dtype([("obs", np.float32, 26), ("reward", np.float64), ("termina
                       ("truncated", np.int32), ("intercepted", np.int32), ("hit_target", np.int32),
                       ("fuze_triggered", np.int32), ("clamped", np.int32), ("distance", np.float32),
                       ("min_distance", np.float32), ("missiles_intercepted", np.int32),
-                      ("missiles_remaining", np.int32)], align=True)
+                      ("missiles_remaining", np.int32), ("fuel_used", np.float32), ("fuel_remaining", np.float32)], align=True)
 
 _lib = None
 

@@ -135,7 +135,7 @@ def replay_oracle(fx, collect=None):
     nz = np.ascontiguousarray(fx["reset_noise0"], np.float64)
     L.orc_reset(C.byref(cfg), C.byref(st), nz.ctypes.data_as(C.POINTER(C.c_double)), obs)
     res = dict(max_obs=0.0, max_reward=0.0, max_distance=0.0, flag_mismatch=[], state={}, int_mismatch=[],
-               reset_obs=0.0, n_steps=len(fx["action"]))
+               reset_obs=0.0, n_steps=len(fx["action"]), fuel_used_bits_differ=0)
     res["reset_obs"] = float(np.max(np.abs(np.array(obs[:]) - fx["reset_obs0"])))
     inject_initial_state(st, fx)
     init_ref = {k[5:]: v for k, v in fx.items() if k.startswith("init_")}
@@ -157,6 +157,8 @@ def replay_oracle(fx, collect=None):
         res["max_reward"] = max(res["max_reward"], abs(out.reward - r_ref) / max(1.0, abs(r_ref)))
         d_ref = float(fx["distance"][t])
         res["max_distance"] = max(res["max_distance"], abs(out.distance - d_ref) / max(1.0, abs(d_ref)))
+        if np.float32(out.fuel_used) != np.float32(fx["fuel_used"][t]):        # info['fuel_used'] (environment.py:834, 886)
+            res["fuel_used_bits_differ"] += 1
         flags = (bool(out.terminated), bool(out.truncated), bool(out.intercepted), bool(out.hit_target))
         ref_flags = (bool(fx["terminated"][t]), bool(fx["truncated"][t]), bool(fx["intercepted"][t]),
                      bool(fx["hit_target"][t]))

@@ -15,8 +15,25 @@ from tests.golden_util import compare_radar_debug, fixture_names, load_fixture, 
 
 pytestmark = pytest.mark.gpu
 
-RTOL = 1e-5          # the bar
-OBS_ATOL = 2e-5      # |obs| <= 2; Kalman-filtered entries carry ~1e-6 of float32 noise amplified by the filter
+RTOL = 1e-5          # the bar (BASELINE.json north_star: 1e-5 relative fp32), for state, reward, distance AND observation:
+OBS_ATOL = 1e-5      # an observation entry x is compared as |x - ref| <= 1e-5 * max(1, |ref|)   (|obs| <= 2)
+LOS_ILL_ATOL = 1.5e-4   # los_frame entries 2, 3, 5 where the reference's own formula is ill-conditioned (_obs_tolerance): as measured
+                        # (tools/soak_oracle.py worst 1.33e-4), not the 5e-4 of round 2
+
+
+def _obs_err(a, b):
+    """[n, 26] observation error in units of the bar: |a - b| / max(1, |b|)."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b) / np.maximum(1.0, np.abs(b))
+
+
+_WORST = {}
+
+
+def _report(test, **worst):
+    """Worst observed value per test (shown with `pytest -rP` / `-s`; also kept for the summary test at the end)."""
+    _WORST[test] = worst
+    print("worst observed:", test, {k: (float(f"{v:.3g}") if isinstance(v, float) else v) for k, v in worst.items()})
 # Per-step reward = 0.8 x (prev_distance - distance): the difference of two ~km float32 numbers, so ONE ulp
 # of a position (2.4e-4 m at 4 km) is a 1e-4 relative change of the reward.  The kernel therefore restates the
 # integrator operation by operation (hlx_device.h).  Where the reference's arithmetic is all +,-,*,/,sqrt
@@ -50,9 +67,9 @@ def _obs_tolerance(rc, ora, done):
     rng = np.linalg.norm(kf[:, 0:3] - so["int_pos"], axis=1)
     loose5 = done | (tv < 2.0)
     loose23 = done | (rng < 100.0)
-    tol[loose5, 5] = 5e-4
-    tol[loose23, 2] = 5e-4
-    tol[loose23, 3] = 5e-4
+    tol[loose5, 5] = LOS_ILL_ATOL
+    tol[loose23, 2] = LOS_ILL_ATOL
+    tol[loose23, 3] = LOS_ILL_ATOL
     return tol
 
 
@@ -179,7 +196,7 @@ def _replay_fixture(name, radar):
 
     env.set_noise(sn_all[0], rn0)
     obs0 = env.reset_torch().cpu().numpy()
-    assert np.max(np.abs(obs0 - fx["reset_obs0"][None])) <= OBS_ATOL
+    assert np.max(_obs_err(obs0, fx["reset_obs0"][None])) <= OBS_ATOL
     # forced edge cases: overwrite the kinematic state the generator tweaked after its first reset
     st = env.get_state()
     for i in range(n):
@@ -221,7 +238,10 @@ def _replay_fixture(name, radar):
             md = info["missile_min_distances"].cpu().numpy()[:K, 0]
             assert np.max(_rel(md, fx["missile_min_distances"][t])) <= 2 * RTOL, (t, md, fx["missile_min_distances"][t])
         step_obs = info["terminal_observation"].cpu().numpy() if fx["did_reset"][t] else obs_h
-        worst["obs"] = max(worst["obs"], float(np.max(np.abs(step_obs - fx["obs"][t][None]))))
+        worst["obs"] = max(worst["obs"], float(np.max(_obs_err(step_obs, fx["obs"][t][None]))))
+        if "fuel_used" in info:    # info['fuel_used'] = total_fuel_used (environment.py:834, 886): the float32 running sum, bit for bit
+            fu = info["fuel_used"].cpu().numpy()
+            assert np.all(fu == np.float32(fx["fuel_used"][t])), (t, fu, fx["fuel_used"][t])
         rew_errs.append(float(np.max(_rel(rew_h, fx["reward"][t]))))
         worst["distance"] = max(worst["distance"], float(np.max(_rel(info["distance"].cpu().numpy(), fx["distance"][t]))))
         assert np.all(obs_h == obs_h[0:1]) and np.all(rew_h == rew_h[0]), "lanes with identical inputs diverged"
@@ -238,8 +258,9 @@ def _replay_fixture(name, radar):
             assert np.max(_rel(info["missile_pos"].cpu().numpy()[:, 0], fx["st_mis_pos"][j])) <= 2 * RTOL, t
             assert int(info["steps"][0]) == int(fx["st_steps"][j]), t
         if fx["did_reset"][t]:
-            worst["reset_obs"] = max(worst["reset_obs"], float(np.max(np.abs(obs_h - fx["reset_obs"][k_reset][None]))))
+            worst["reset_obs"] = max(worst["reset_obs"], float(np.max(_obs_err(obs_h, fx["reset_obs"][k_reset][None]))))
             k_reset += 1
+    _report(f"fixture {name}" + (" (radar)" if radar is not None else ""), reward=max(rew_errs, default=0.0), **worst)
     assert worst["obs"] <= OBS_ATOL, worst
     assert worst["reset_obs"] <= OBS_ATOL, worst
     assert not radar_bad, (len(radar_bad), radar_bad[:5])
@@ -308,7 +329,7 @@ def test_gpu_matches_oracle_free_running(scenario, physics, over, variant, late)
     # reset both from the same Philox draws
     obs_g = env.reset_torch().cpu().numpy()
     obs_o = ora.reset(rn.cpu().numpy().T.copy())
-    assert np.max(np.abs(obs_g - obs_o)) <= OBS_ATOL
+    assert np.max(_obs_err(obs_g, obs_o)) <= OBS_ATOL
     alive = np.ones(n, bool)     # envs whose discrete history still agrees
     n_done_total = 0
     worst = dict(obs=0.0, distance=0.0)
@@ -330,7 +351,7 @@ def test_gpu_matches_oracle_free_running(scenario, physics, over, variant, late)
         term_obs = info["terminal_observation"].cpu().numpy()
         step_obs_g = np.where(done[:, None], term_obs, obs_h)
         step_obs_o = np.where(done[:, None], ora.terminal_obs, out["obs"])
-        eo = np.max(np.abs(step_obs_g - step_obs_o) * (OBS_ATOL / _obs_tolerance(rc, ora, done)), axis=1)
+        eo = np.max(_obs_err(step_obs_g, step_obs_o) * (OBS_ATOL / _obs_tolerance(rc, ora, done)), axis=1)
         er = _rel(rew.cpu().numpy(), out["reward"])
         ed = _rel(info["distance"].cpu().numpy(), out["distance"])
         # an env whose observation jumps (a detection decided differently at a float32 boundary) is retired
@@ -342,7 +363,9 @@ def test_gpu_matches_oracle_free_running(scenario, physics, over, variant, late)
         if done.any():
             sel = done & alive
             if sel.any():
-                assert np.max(np.abs(obs_h[sel] - out["obs"][sel])) <= OBS_ATOL
+                assert np.max(_obs_err(obs_h[sel], out["obs"][sel])) <= OBS_ATOL
+        fu_bad = info["fuel_used"].cpu().numpy() != out["fuel_used"]
+        assert not fu_bad[alive].any(), (t, int(fu_bad.sum()))       # info['fuel_used']: bit for bit
     # detection decisions are taken with the reference's own arithmetic near their thresholds (hlx_kernels.hip): no environment
     # may leave the oracle's discrete history -- round 1 tolerated 0.5 % of them
     assert alive.all(), f"{(~alive).sum()} of {n} envs diverged in their discrete history"
@@ -355,12 +378,18 @@ def test_gpu_matches_oracle_free_running(scenario, physics, over, variant, late)
         ref = ora.field(name)
         mine = np.array([list(getattr(st[i], name)) for i in range(n)])
         assert np.max(_rel(mine[alive], ref[alive])) <= 2 * RTOL, name
+    # the Kalman filter: observed bit-identical covariance and <= 3e-5 m of position estimate (tools/soak_oracle.py); the bounds
+    # are 1e-6 relative, a tenth of the bar (round 2 allowed 5e-5 / 1e-3: a hundredfold regression would have passed)
     kx = np.array([list(st[i].kf_x) for i in range(n)])
-    assert np.max(_rel(kx[alive][:, :3], ora.field("kf_x")[alive][:, :3])) <= 5 * RTOL
+    kx_err = float(np.max(_rel(kx[alive][:, :3], ora.field("kf_x")[alive][:, :3])))
     P = np.array([list(st[i].kf_P) for i in range(n)])
     Po = ora.field("kf_P").reshape(n, 6, 6)
     Pref = np.stack([Po[:, 0, 0], Po[:, 0, 3], Po[:, 3, 0], Po[:, 3, 3]], axis=1)
-    assert np.max(np.abs(P[alive] - Pref[alive]) / np.maximum(1e-2, np.abs(Pref[alive]))) <= 1e-3
+    kp_err = float(np.max(np.abs(P[alive] - Pref[alive]) / np.maximum(1e-2, np.abs(Pref[alive]))))
+    _report(f"free-running {variant} {scenario}/{physics} late={late}", reward=float(np.concatenate(rew_errs).max(initial=0.0)),
+            kf_x_pos=kx_err, kf_P=kp_err, **worst)
+    assert kx_err <= 1e-6, kx_err
+    assert kp_err <= 1e-6, kp_err
     steps_g = np.array([st[i].steps for i in range(n)])
     assert np.array_equal(steps_g[alive], ora.field("steps")[alive])
     if rc.volley_mode:
@@ -406,12 +435,13 @@ def test_gpu_matches_oracle_from_identical_state(scenario, physics, over, varian
         flag_mismatch += int((~same).sum())
         step_obs_g = np.where(done[:, None], info["terminal_observation"].cpu().numpy(), obs.cpu().numpy())
         step_obs_o = np.where(done[:, None], ora.terminal_obs, out["obs"])
-        eo = np.max(np.abs(step_obs_g - step_obs_o) * (OBS_ATOL / _obs_tolerance(rc, ora, done)), axis=1)
+        eo = np.max(_obs_err(step_obs_g, step_obs_o) * (OBS_ATOL / _obs_tolerance(rc, ora, done)), axis=1)
         ok = same & (eo <= 50 * OBS_ATOL)          # a Bernoulli detection decided at a float32 boundary is retired
         flag_mismatch += int((same & ~ok).sum())
         worst_obs = max(worst_obs, float(eo[ok].max(initial=0.0)))
         worst_dist = max(worst_dist, float(_rel(info["distance"].cpu().numpy(), out["distance"])[ok].max(initial=0.0)))
         rew_errs.append(_rel(rew.cpu().numpy(), out["reward"])[ok])
+    _report(f"resynced {variant} {scenario}/{physics}", obs=worst_obs, distance=worst_dist, reward=float(np.concatenate(rew_errs).max(initial=0.0)))
     assert flag_mismatch == 0, flag_mismatch
     assert worst_obs <= OBS_ATOL and worst_dist <= RTOL, (worst_obs, worst_dist)
     _check_reward_errors(np.concatenate(rew_errs), rc, (scenario, physics), resynced=True)
@@ -437,7 +467,7 @@ def test_full_size_batch_matches_oracle(physics, variant):
     sn, rn = env.fill_noise(for_reset=True)
     obs_g = env.reset_torch().cpu().numpy()
     obs_o = ora.reset(rn.cpu().numpy().T.copy())
-    assert np.max(np.abs(obs_g - obs_o)) <= OBS_ATOL
+    assert np.max(_obs_err(obs_g, obs_o)) <= OBS_ATOL
     alive = np.ones(n, bool)
     worst = dict(obs=0.0, distance=0.0, reset_obs=0.0)
     rew_errs, n_done = [], 0
@@ -453,14 +483,15 @@ def test_full_size_batch_matches_oracle(physics, variant):
         obs_h = obs.cpu().numpy()
         step_obs_g = np.where(done[:, None], info["terminal_observation"].cpu().numpy(), obs_h)
         step_obs_o = np.where(done[:, None], ora.terminal_obs, out["obs"])
-        eo = np.max(np.abs(step_obs_g - step_obs_o) * (OBS_ATOL / _obs_tolerance(rc, ora, done)), axis=1)
+        eo = np.max(_obs_err(step_obs_g, step_obs_o) * (OBS_ATOL / _obs_tolerance(rc, ora, done)), axis=1)
         alive &= eo <= 50 * OBS_ATOL             # a Bernoulli detection decided at a float32 boundary retires the env
         worst["obs"] = max(worst["obs"], float(eo[alive].max(initial=0.0)))
         rew_errs.append(_rel(rew.cpu().numpy(), out["reward"])[alive])
         worst["distance"] = max(worst["distance"], float(_rel(info["distance"].cpu().numpy(), out["distance"])[alive].max(initial=0.0)))
         sel = done & alive
         if sel.any():
-            worst["reset_obs"] = max(worst["reset_obs"], float(np.max(np.abs(obs_h[sel] - out["obs"][sel]))))
+            worst["reset_obs"] = max(worst["reset_obs"], float(np.max(_obs_err(obs_h[sel], out["obs"][sel]))))
+    _report(f"full size {physics}", reward=float(np.concatenate(rew_errs).max(initial=0.0)), **worst)
     assert n_done >= n, "every environment must have restarted inside the window"
     assert alive.all(), f"{(~alive).sum()} of {n} envs diverged in their discrete history"
     assert worst["obs"] <= OBS_ATOL and worst["reset_obs"] <= OBS_ATOL, worst

@@ -6,10 +6,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _env(n, physics="base", over=None, seed=3):
+def _env(n, physics="base", over=None, seed=3, offset=0):
     from hlynr_intercept_amd.scenarios import scenario_config
     from hlynr_intercept_amd.vec_env import HlynrVecEnv
-    return HlynrVecEnv(scenario_config("medium", physics, over), num_envs=n, seed=seed)
+    return HlynrVecEnv(scenario_config("medium", physics, over), num_envs=n, seed=seed, env_id_offset=offset)
 
 
 def test_sb3_vecenv_contract_and_auto_reset():
@@ -470,3 +470,139 @@ def test_single_observation_pass_equals_the_two_pass_form():
     assert n_done > 5 * n and bytes(a_env.get_state()) == bytes(c_env.get_state())
     for e in (a_env, b_env, c_env):
         e.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# round 3: the contract form through hlx_rollout, the caller-owned done counter, reset epochs, reset(options=...)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("physics,volley", [("base", False), ("v2dr", False), ("config", True)])
+def test_rollout_contract_form_issues_exactly_the_hlx_step_launch(physics, volley):
+    """`hlx_set_rollout_outputs` + `hlx_rollout` (what bench.py times) against `hlx_step` called step by step (what
+    `HlynrVecEnv.step_torch` issues): observations, rewards, flags, terminal observations, every info plane, the done
+    list, its length in the caller-owned counter and the final state, bit for bit, across several auto-resets."""
+    import torch
+    over = {"max_steps": 23}
+    if volley:
+        over.update(volley_mode=True, volley_size=3)
+    n, T = 700, 90
+    a_env, b_env = _env(n, physics=physics, over=over, seed=31), _env(n, physics=physics, over=over, seed=31)
+    a_env.reset_torch(); b_env.reset_torch()
+    g = torch.Generator(device=a_env.device).manual_seed(8)
+    tape = torch.rand((T, n, 6), generator=g, device=a_env.device) * 2 - 1
+    b_env.set_rollout_contract(True, done_list=True)
+    planes = [k for k in a_env.info if k not in ("episode_return", "episode_length")]
+    seen_done = 0
+    for t in range(T):
+        obs, rew, term, trunc, info = a_env.step_torch(tape[t], want_done_list=True)
+        o, r, te, tr = b_env.rollout_torch(tape[t:t + 1], 1)
+        assert torch.equal(obs, o[0]) and torch.equal(rew, r[0]) and torch.equal(term, te[0]) and torch.equal(trunc, tr[0]), t
+        done = (term | trunc) != 0
+        nd = int(info["n_done"].item())
+        assert nd == int(done.sum()) == int(b_env.n_done_pair[int(b_env._lib.hlx_vec_steps(b_env._h)) & 1].item()), t
+        seen_done += nd
+        assert torch.equal(torch.sort(a_env.done_idx[:nd]).values, torch.sort(b_env.done_idx[:nd]).values)
+        for k in planes:
+            assert torch.equal(a_env.info[k], b_env.info[k]), (t, k)
+        if nd:
+            assert torch.equal(a_env.terminal_obs[done], b_env.terminal_obs[done]), t
+            for k in ("episode_return", "episode_length"):
+                assert torch.equal(a_env.info[k][done], b_env.info[k][done]), (t, k)
+    assert seen_done > 3 * n
+    assert bytes(a_env.get_state()) == bytes(b_env.get_state())
+    # ... and without the outputs the rollout is the single-pass form again: same observations, rewards, flags, state
+    b_env.set_rollout_contract(False)
+    obs, rew, term, trunc, info = a_env.step_torch(tape[0])
+    o, r, te, tr = b_env.rollout_torch(tape[0:1], 1)
+    assert torch.equal(obs, o[0]) and torch.equal(rew, r[0]) and torch.equal(term, te[0]) and torch.equal(trunc, tr[0])
+    assert bytes(a_env.get_state()) == bytes(b_env.get_state())
+    a_env.close(); b_env.close()
+
+
+def test_fuel_used_accumulates_like_the_reference():
+    """info['fuel_used'] = `total_fuel_used` (environment.py:566, 834, 886): a float32 running sum restarted by every reset;
+    checked here against a float32 host accumulation of the same per-step consumption (the oracle comparison is in
+    test_gpu_parity: bit for bit in every fixture and free-running case)."""
+    import torch
+    n = 512
+    env = _env(n, physics="v2", over={"max_steps": 17}, seed=6)
+    env.reset_torch()
+    g = torch.Generator(device=env.device).manual_seed(2)
+    for t in range(60):
+        a = torch.rand((n, 6), generator=g, device=env.device) * 2 - 1
+        obs, rew, term, trunc, info = env.step_torch(a)
+        fu, fuel = info["fuel_used"].cpu().numpy(), info["fuel"].cpu().numpy()
+        steps = info["steps"].cpu().numpy()
+        assert np.all(fu > 0) and np.all(fu <= 100.0 * 1.01)
+        assert np.all(fu[steps == 1] <= 0.04)                        # restarted with the episode
+        assert np.all(np.abs(fu - (100.0 - fuel)) <= 2e-3)           # what round 2 reported instead, equal up to rounding
+    env.close()
+
+
+def test_reset_epoch_counts_resets_at_one_clock_value_and_is_shard_independent():
+    """The advisor's scenario: a masked reset on ONE shard followed by a full reset must equal the unsharded
+    run when every shard sees the same hlx_reset calls; the epoch restarts once a step has advanced the clock; a caller
+    that skips shards with an empty mask slice can keep them in step with hlx_set_reset_epoch."""
+    import torch
+    from hlynr_intercept_amd import _lib as hl
+    n, cut = 384, 128
+    whole = _env(n, seed=9)
+    lo, hi = _env(cut, seed=9, offset=0), _env(n - cut, seed=9, offset=cut)
+    mask = torch.zeros(n, dtype=torch.uint8, device=whole.device)
+    mask[5:40] = 1                                        # only environments of the FIRST shard
+    for e in (whole, lo, hi):
+        e.reset_torch()
+    assert torch.equal(whole.obs, torch.cat([lo.obs, hi.obs]))
+    assert whole._lib.hlx_get_reset_epoch(whole._h) == 1
+    whole.reset_torch(mask); lo.reset_torch(mask[:cut]); hi.reset_torch(mask[cut:])      # every shard sees the masked reset
+    whole.reset_torch(); lo.reset_torch(); hi.reset_torch()
+    assert torch.equal(whole.obs, torch.cat([lo.obs, hi.obs]))
+    first = whole.obs.clone()
+    # a caller that skipped the second shard (its mask slice is all zero) sets the epoch instead
+    whole2, lo2, hi2 = _env(n, seed=9), _env(cut, seed=9, offset=0), _env(n - cut, seed=9, offset=cut)
+    for e in (whole2, lo2, hi2):
+        e.reset_torch()
+    whole2.reset_torch(mask); lo2.reset_torch(mask[:cut])
+    hl.check(hi2._lib.hlx_set_reset_epoch(hi2._h, lo2._lib.hlx_get_reset_epoch(lo2._h)))
+    whole2.reset_torch(); lo2.reset_torch(); hi2.reset_torch()
+    assert torch.equal(whole2.obs, torch.cat([lo2.obs, hi2.obs])) and torch.equal(whole2.obs, first)
+    # two resets with no step between them start different episodes; after a step the epoch is 0 again
+    assert not torch.equal(whole.reset_torch().clone(), first)
+    whole.step_torch(torch.zeros((n, 6), device=whole.device))
+    assert whole._lib.hlx_get_reset_epoch(whole._h) == 0
+    with pytest.raises(hl.HlxError, match="16 bits"):
+        hl.check(whole._lib.hlx_set_reset_epoch(whole._h, 1 << 16))
+    for e in (whole, lo, hi, whole2, lo2, hi2):
+        e.close()
+
+
+def test_reset_options_switch_volley_mode_like_the_reference():
+    """environment.py:363-366: `reset(options={'volley_mode': ..., 'volley_size': ...})` overrides the configuration from
+    that reset on.  Volley mode is a code-generation flag here, so the facade re-creates its handle with the other
+    instantiation; the result must be the environment one gets by configuring volley mode up front."""
+    import torch
+    from hlynr_intercept_amd.config import resolve_config
+    from hlynr_intercept_amd.scenarios import scenario_config
+    from hlynr_intercept_amd.vec_env import HlynrVecEnv
+    n = 256
+    env = HlynrVecEnv(resolved=resolve_config(scenario_config("medium", "config")), num_envs=n, seed=4)
+    assert env.kernel_variant == "config"
+    env.reset()
+    ref = HlynrVecEnv(resolved=resolve_config(scenario_config("medium", "config", {"volley_mode": True, "volley_size": 3})), num_envs=n, seed=4)
+    o_ref = ref.reset()
+    o = env.reset(options={"volley_mode": True, "volley_size": 3})
+    assert env.kernel_variant == "config-volley" and env.rc.volley_size == 3
+    assert np.array_equal(o, o_ref)
+    a = torch.zeros((n, 6), device=env.device)
+    for _ in range(5):
+        x, y = env.step_torch(a), ref.step_torch(a)
+        assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1])
+        assert torch.equal(x[4]["missile_min_distances"], y[4]["missile_min_distances"])
+    infos = env.step(np.zeros((n, 6), np.float32))[3]
+    assert infos[0]["volley_mode"] is True and infos[0]["volley_size"] == 3 and len(infos[0]["missile_min_distances"]) == 3
+    env.reset()                                            # no options: the override stays in force (the reference's attributes do)
+    assert env.kernel_variant == "config-volley"
+    env.reset(options={})                                  # options without the keys fall back to the CONFIG's values
+    assert env.kernel_variant == "config" and not env.rc.volley_mode
+    with pytest.raises(ValueError):
+        env.reset(options={"volley_mode": True, "volley_size": 9})
+    env.close(); ref.close()
