@@ -419,4 +419,50 @@ DEV void los_basis(V3 lu, V3& h, V3& v) {
     v = cross(lu, h);
 }
 
+// core.py:802-868 (los_frame: LOS rates obs[2:4], lead-angle cosine obs[5]) REPLAYED operation by operation, in the dtype the
+// reference computes in: float64 once the Kalman state is (oracle/hlx_oracle.c observe(), `f64`), float32 before.  The fast
+// float32 formulas of the observation section are good to ~1e-7 of their largest intermediate -- a closing speed of
+// ~1000 m/s -- and the LOS rates divide that by the filtered range: under a few hundred metres (the end of every successful
+// pursuit; under a metre when the filter was initialised from an empty delay-line sample) the quotient no longer holds
+// 1e-5.  Used only there (out of line, los_frame configurations only).
+struct LosExact { float rate_h, rate_v, lead_cos; };
+DEV LosExact los_exact64(D3 kxp, D3 kxv, V3 ipos, V3 ivel) {
+    const D3 frp = kxp - to_d3(ipos), frv = kxv - to_d3(ivel);                          // :758-759
+    const double rng = sqrt(ddot(frp, frp));
+    const double closing = -ddot(frp, frv) / (rng + 1e-6);                              // :786
+    const D3 lu = (rng > 1e-6) ? D3{frp.x / rng, frp.y / rng, frp.z / rng} : D3{1.0, 0.0, 0.0};
+    const double den = rng + 1e-6;
+    const D3 rate = D3{(frv.x - closing * lu.x) / den, (frv.y - closing * lu.y) / den, (frv.z - closing * lu.z) / den};   // :810-811
+    // np.cross(los_unit, [0, 0, 1]) and np.cross(los_unit, h): cp = a1*b2 - a2*b1, ... (:824-834)
+    const D3 right = D3{lu.y * 1.0 - lu.z * 0.0, lu.z * 0.0 - lu.x * 1.0, lu.x * 0.0 - lu.y * 0.0};
+    const double n = sqrt(ddot(right, right));
+    const D3 h = (n > 1e-6) ? D3{right.x / n, right.y / n, right.z / n} : D3{1.0, 0.0, 0.0};
+    const D3 v = D3{lu.y * h.z - lu.z * h.y, lu.z * h.x - lu.x * h.z, lu.x * h.y - lu.y * h.x};
+    LosExact o;
+    o.rate_h = (float)fmin(fmax(ddot(rate, h) / 0.5, -1.0), 1.0);                       // :844-845
+    o.rate_v = (float)fmin(fmax(ddot(rate, v) / 0.5, -1.0), 1.0);                       // :848-849
+    const D3 tv = frv + to_d3(ivel);                                                    // :861
+    const double tvm = sqrt(ddot(tv, tv));
+    o.lead_cos = (tvm > 1e-6) ? (float)ddot(D3{tv.x / tvm, tv.y / tvm, tv.z / tvm}, D3{-lu.x, -lu.y, -lu.z}) : 0.f;   // :862-868
+    return o;
+}
+DEV LosExact los_exact32(V3 frp, V3 frv, V3 ivel) {      // IEEE float32 divisions (the compiler's), numpy's float32 dot / norm
+    const float rng = snorm3(frp);
+    const float den = rng + 1e-6f;
+    const float closing = -(sdot3(frp, frv) / den);
+    const V3 lu = (rng > 1e-6f) ? V3{frp.x / rng, frp.y / rng, frp.z / rng} : v3(1.f, 0.f, 0.f);
+    const V3 rate = V3{(frv.x - closing * lu.x) / den, (frv.y - closing * lu.y) / den, (frv.z - closing * lu.z) / den};
+    const V3 right = cross(lu, v3(0.f, 0.f, 1.f));
+    const float n = snorm3(right);
+    const V3 h = (n > 1e-6f) ? V3{right.x / n, right.y / n, right.z / n} : v3(1.f, 0.f, 0.f);
+    const V3 v = cross(lu, h);
+    LosExact o;
+    o.rate_h = clampf(sdot3(rate, h) / 0.5f, -1.f, 1.f);
+    o.rate_v = clampf(sdot3(rate, v) / 0.5f, -1.f, 1.f);
+    const V3 tv = v3(frv.x + ivel.x, frv.y + ivel.y, frv.z + ivel.z);
+    const float tvm = snorm3(tv);
+    o.lead_cos = (tvm > 1e-6f) ? sdot3(V3{tv.x / tvm, tv.y / tvm, tv.z / tvm}, v3(-lu.x, -lu.y, -lu.z)) : 0.f;
+    return o;
+}
+
 }  // namespace hlx

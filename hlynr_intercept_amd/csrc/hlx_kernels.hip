@@ -55,6 +55,14 @@ namespace {
 #define HLX_INFO_RARE 0
 #endif
 #define INFO_WANTED(x) (HLX_INFO_RARE ? RARE(x) : (x))
+// Pointers that reach the kernel through the hot block (optional outputs) or through *P are GENERIC to the compiler, and a
+// generic access is a FLAT instruction: it counts in vmcnt AND lgkmcnt, may complete out of order with the global ones, and while
+// one may be pending every later `s_waitcnt vmcnt(n)` the compiler emits becomes vmcnt(0) -- on every path, taken or not.  (Found
+// in round 3: one flat_load for the info['fuel_used'] accumulator turned the wait for the missile groups into a wait for the
+// whole second load batch, 0.45 us per launch in every form of the step; the info planes' flat stores made each later
+// `lgkmcnt(0)` of the LDS tile hand-over wait for their acknowledgements.)  G(p) says what they are: global memory.
+template <typename T> using gptr_t = __attribute__((address_space(1))) T*;
+template <typename T> DEV gptr_t<T> G(T* p) { return (gptr_t<T>)p; }
 
 // Diagnostic build only (-DHLX_STAMPS): lane 0 of every wave records s_memtime at a few program points into
 // a.stamps[block][16].  No stamp executes in the product build, and no output is ever computed from one.
@@ -222,7 +230,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
     // while the loads are in flight.  The Kalman groups and the ring sample follow as a second batch after Philox.
     float4 g_ipos = A[G_IPOS * 64], g_ivel = A[G_IVEL * 64], g_quat = A[G_QUAT * 64], g_w1 = A[G_W1 * 64];
     double2 g_w0 = AD[G_W0 * 64];
-    float4 g_mpos = A[G_MPOS * 64], g_mvel = A[G_MVEL * 64];   // first needed a whole integrator section later than the others
+    // The missile's groups are released (waited for) where the missile is integrated, a whole interceptor section later --
+    // unless something reads the missile earlier (LOS-frame actions, the volley's bookkeeping, a reset-only launch).
+    // (with the v2 models the second batch is long enough already: 11.40 against 11.46 us, profiles/r02_ab_missile_groups_waited_late.txt)
+    constexpr bool missile_late = MODE == 0 && !((SPEC & KF_DYNAMIC) != 0) && !(SPEC & (HLX_F_OBS_LOS | HLX_F_VOLLEY | HLX_F_ATMOSPHERE));
+    // ... and in the small-batch schedule they are LOADED with the second batch, at its head (until round 3 that was the compiler's
+    // doing -- it sank the two loads to their first use -- and an unrelated edit undid it; now it is written down)
+#ifndef HLX_MISSILE_LOADS_LATE
+#define HLX_MISSILE_LOADS_LATE 1
+#endif
+    constexpr bool missile_loads_late = HLX_MISSILE_LOADS_LATE && missile_late && LATE && !PERSIST;
+    float4 g_mpos = make_float4(0.f, 0.f, 0.f, 0.f), g_mvel = g_mpos;
+    if (!missile_loads_late) { g_mpos = A[G_MPOS * 64]; g_mvel = A[G_MVEL * 64]; }
     float4 g_thr = make_float4(0.f, 0.f, 0.f, 0.f), g_misc = g_thr;
     if (HAS(HLX_F_THRUST_LAG) || HAS(HLX_F_DOMAIN_RAND)) g_thr = A[G_THRUST * 64];   // .w: a domain-randomised constant
     if (HAS(HLX_F_DOMAIN_RAND)) g_misc = A[G_MISC * 64];
@@ -279,6 +298,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         }
 
         STAMP(1);   // all loads issued
+        // ... and nothing of the Philox block below may be scheduled in front of them.  (Round 3: an edit far below -- the
+        // info['fuel_used'] accumulator -- made the machine scheduler hoist the first two Philox rounds, ~60 instructions, above the
+        // state loads of the base kernel: the loads left ~350 cycles later and every form of the step lost 0.5 us, old
+        // against new library on one box, profiles/r03_ab_loads_before_philox.txt.)
+#ifndef HLX_NO_LOAD_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         const bool noise_buf = NOISE && P->hot.opt.step_noise != nullptr;    // parity instantiation only
         const bool rnoise_buf = NOISE && P->hot.opt.reset_noise != nullptr;
         const unsigned long long gid = (unsigned long long)(env_offset + i);
@@ -343,16 +369,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             // move while the physics runs.  `late` is an opaque zero that pins them below Philox.
             uint32_t late = 0;
             asm volatile("" : "+v"(late));
+            if (missile_loads_late) { g_mpos = A[G_MPOS * 64 + late]; g_mvel = A[G_MVEL * 64 + late]; }
             if (MODE == 0 && HAS(HLX_F_GROUND)) {   // unconditional when the station exists (the host always allocates >= 1 slot)
                 const float4* R = gring + ((size_t)g_rslot * GROUND_RING_WORDS16) * N + ic + late;   // slot (t - g_delay) mod cap
                 gr0 = *reinterpret_cast<const double2*>(R); gr1 = R[N]; gr2 = R[2 * N];
             }
             if (!PERSIST) { g_kfp = A[G_KFP * 64 + late]; g_kf0 = AD[G_KF0 * 64 + late]; g_kf1 = AD[G_KF1 * 64 + late]; g_kf2 = AD[G_KF2 * 64 + late]; }
         }
-        // The missile's groups are released (waited for) where the missile is integrated, a whole interceptor section later --
-        // unless something reads the missile earlier (LOS-frame actions, the volley's bookkeeping, a reset-only launch).
-        // (with the v2 models the second batch is long enough already: 11.40 against 11.46 us, profiles/r02_ab_missile_groups_waited_late.txt)
-        constexpr bool missile_late = MODE == 0 && !((SPEC & KF_DYNAMIC) != 0) && !(SPEC & (HLX_F_OBS_LOS | HLX_F_VOLLEY | HLX_F_ATMOSPHERE));
         PIN4(g_ipos); PIN4(g_ivel); PIN4(g_quat); PIN4(g_w1); PIN2(g_w0);
         if (!missile_late) { PIN4(g_mpos); PIN4(g_mvel); }
         if (HAS(HLX_F_THRUST_LAG) || HAS(HLX_F_DOMAIN_RAND)) PIN4(g_thr);
@@ -370,7 +393,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         // info['fuel_used'] (environment.py:886) accumulates in the CALLER's plane (hlx.h): last step's value is fetched here, as
         // soon as the hot words can be read, and is first needed in the info block a whole physics section later
         float fuel_used_prev = 0.f;
-        if (MODE == 0 && INFO_WANTED(slots & (1u << 20)) && HOT(opt.info.fuel_used)) fuel_used_prev = HOT(opt.info.fuel_used)[ic];
+        if (MODE == 0 && INFO_WANTED(slots & (1u << 20)) && HOT(opt.info.fuel_used)) fuel_used_prev = G(HOT(opt.info.fuel_used))[ic];
         if (live) {   // ============================== per-environment work, live lanes only ==============================
         STAMP(2);   // Philox block done (loads still in flight)
         V3 ipos = v3(g_ipos.x, g_ipos.y, g_ipos.z), ivel = v3(g_ivel.x, g_ivel.y, g_ivel.z);
@@ -731,7 +754,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             ep_return += reward;
         } else {
             // reset-only launch: `done` marks the envs to reset
-            done = HOT(opt.reset_mask) ? (HOT(opt.reset_mask)[i] != 0) : true;
+            done = HOT(opt.reset_mask) ? (G(HOT(opt.reset_mask))[i] != 0) : true;
         }
 
         STAMP(7);   // reward
@@ -749,20 +772,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             term_out[i] = terminated ? 1 : 0;
             trunc_out[i] = truncated ? 1 : 0;
             if (INFO_WANTED(slots & (1u << 20))) {   // some hlx_info_soa plane is wanted (one SGPR test instead of nine pointer fetches)
-            if (HOT(opt.info.distance)) HOT(opt.info.distance)[i] = distance;
-            if (HOT(opt.info.min_distance)) HOT(opt.info.min_distance)[i] = min_distance;
-            if (HOT(opt.info.fuel)) HOT(opt.info.fuel)[i] = fuel;
+            if (HOT(opt.info.distance)) G(HOT(opt.info.distance))[i] = distance;
+            if (HOT(opt.info.min_distance)) G(HOT(opt.info.min_distance))[i] = min_distance;
+            if (HOT(opt.info.fuel)) G(HOT(opt.info.fuel))[i] = fuel;
             if (HOT(opt.info.fuel_used))    // :886 `self.total_fuel_used += fuel_consumed` (float32; 0 at reset, :566)
-                HOT(opt.info.fuel_used)[i] = (steps == 1) ? fuel_step : fuel_used_prev + fuel_step;
+                G(HOT(opt.info.fuel_used))[i] = (steps == 1) ? fuel_step : fuel_used_prev + fuel_step;
             if (HOT(opt.info.interceptor_pos)) {                                  // :836-838 (post-step, pre-respawn values)
-                float* ip = HOT(opt.info.interceptor_pos) + i;
+                auto ip = G(HOT(opt.info.interceptor_pos)) + i;
                 ip[0] = ipos.x; ip[(size_t)n] = ipos.y; ip[2 * (size_t)n] = ipos.z;
             }
             if (HOT(opt.info.missile_pos)) {
-                float* mp = HOT(opt.info.missile_pos) + i;
+                auto mp = G(HOT(opt.info.missile_pos)) + i;
                 mp[0] = mpos.x; mp[(size_t)n] = mpos.y; mp[2 * (size_t)n] = mpos.z;
             }
-            if (HOT(opt.info.steps)) HOT(opt.info.steps)[i] = steps;
+            if (HOT(opt.info.steps)) G(HOT(opt.info.steps))[i] = steps;
             if (HOT(opt.info.missiles)) {                                                 // :846-847
                 int remaining = intercepted ? 0 : 1, got = intercepted ? 1 : 0;
                 if (HAS(HLX_F_VOLLEY)) {
@@ -770,10 +793,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
 #pragma unroll
                     for (int k = 0; k < HLX_MAX_VOLLEY; ++k) remaining += (k < VK && vact[k]) ? 1 : 0;
                 }
-                HOT(opt.info.missiles)[i] = (uint8_t)(got | (remaining << 4));
+                G(HOT(opt.info.missiles))[i] = (uint8_t)(got | (remaining << 4));
             }
             if (HAS(HLX_F_VOLLEY) && HOT(opt.info.missile_min_distances)) {               // :848
-                float* md = HOT(opt.info.missile_min_distances) + i;
+                auto md = G(HOT(opt.info.missile_min_distances)) + i;
 #pragma unroll
                 for (int k = 0; k < HLX_MAX_VOLLEY; ++k) if (k < VK) md[(size_t)k * (size_t)n] = vmin[k];
             }
@@ -904,8 +927,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
 #pragma unroll
                             for (int k = 0; k < HLX_OBS_DIM / 2; ++k) to[k] = tv[k];
                         }
-                        if (HOT(opt.info.episode_return)) HOT(opt.info.episode_return)[i] = ep_return;
-                        if (HOT(opt.info.episode_length)) HOT(opt.info.episode_length)[i] = steps;
+                        if (HOT(opt.info.episode_return)) G(HOT(opt.info.episode_return))[i] = ep_return;
+                        if (HOT(opt.info.episode_length)) G(HOT(opt.info.episode_length))[i] = steps;
                     }
                     // ---------------- spawn (environment.py:375-567): float64 draws cast to float32
                     const bool rbuf = rnoise_buf;
@@ -1089,7 +1112,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     }
                     g_det = g_det && !(mpos.z < 50.f);                              // :409
                     float dpq = ((HOT(c.g_base_q) * (1.0f - (grange * HOT(c.inv_g_max_range)) * 0.4f)) * HOT(c.weather)) * HOT(cur.g_rel);   // :413-418
-                    if (RARE(g_det && fabsf(n_g - dpq) < 2e-6f))
+                    // The reference's own operations where the Bernoulli draw is within reach of the fast value's error -- and always in
+                    // los_frame mode: the quality is also the measurement's WEIGHT in the fusion below (core.py:735-738), an ulp of it is
+                    // 3e-8 of the fused position, and the LOS-frame lead angle / LOS rates amplify exactly that when the velocity estimate
+                    // or the range is small (found with tools/diag_kf.py: the filter state differed by 2e-8 relative from the first
+                    // float64 measurement on).  Elsewhere no output shows it above 4e-6 and the step keeps the cheap form.
+                    if (HAS(HLX_F_OBS_LOS) || RARE(g_det && fabsf(n_g - dpq) < 2e-6f))
                         dpq = ((HOT(c.g_base_q) * (1.0f - HLX_DIVF(snorm3(g2m), HOT(c.g_max_range)) * 0.4f)) * HOT(c.weather)) * HOT(cur.g_rel);
                     g_det = g_det && !(n_g > dpq);
                     if (g_det) {
@@ -1143,7 +1171,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     // detected or not, and 0.0 only while the delay line is still filling
                     det_bits = (d_on_det ? 32u : 0u) | (d_g_det ? 64u : 0u) | ((HOT(c.o_delay) == 0 || steps >= on_delay) ? 128u : 0u);
                     if (HAS(HLX_F_RADAR_DEBUG) && (slots & (1u << 20)) && HOT(opt.info.radar_debug)) {     // what info['radar_debug'] (core.py:650-683) cannot rebuild from positions
-                        float* rd = HOT(opt.info.radar_debug) + i;
+                        auto rd = G(HOT(opt.info.radar_debug)) + i;
                         rd[0] = q.w; rd[N] = q.x; rd[2 * N] = q.y; rd[3 * N] = q.z;
                         rd[4 * N] = d_gq;
                         rd[5 * N] = __int_as_float((int)(-on_why) | (g_det ? 8 : 0));
@@ -1262,6 +1290,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                                        : v3(frv.x + ivel.x, frv.y + ivel.y, frv.z + ivel.z);   // :861
                         float tvm = fnorm_out(tv);
                         row[5] = (tvm > 1e-6f) ? -fdiv(fdot(tv, lu), tvm) : 0.f;
+                        // close in (or with next to no velocity estimate) the fast formulas above no longer hold 1e-5 on the LOS rates
+                        // and the lead angle: the reference's own arithmetic, in the reference's dtype (hlx_device.h los_exact*)
+                        if (RARE(rrange < 300.f || tvm < 2.f)) {
+                            const LosExact e = kf_x64 ? los_exact64(kxp, kxv, ipos, ivel) : los_exact32(frp, frv, ivel);
+                            row[2] = e.rate_h; row[3] = e.rate_v; row[5] = e.lead_cos;
+                        }
                         row[6] = clampf(ivm * inv_mv, 0.f, 1.f);                    // :924-925
                         row[7] = clampf(fdot(ivel, h) * inv_mv, -1.f, 1.f);         // :948-953
                         row[8] = clampf(fdot(ivel, v) * inv_mv, -1.f, 1.f);
@@ -1390,7 +1424,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         }
         if (MODE == 0) {
             if ((slots & (1u << 20)) && HOT(opt.info.flags))
-                HOT(opt.info.flags)[i] = (uint8_t)((intercepted ? 1u : 0u) | (hit_target ? 2u : 0u) | (fuze ? 4u : 0u) |
+                G(HOT(opt.info.flags))[i] = (uint8_t)((intercepted ? 1u : 0u) | (hit_target ? 2u : 0u) | (fuze ? 4u : 0u) |
                                             (clamped ? 8u : 0u) | (crossed ? 16u : 0u) | det_bits);
         }
         }   // if (live)
@@ -1402,14 +1436,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         const unsigned long long m = __ballot(live && done);
         if (m) {
             int base = 0;
-            if (lane == 0) base = atomicAdd(P->done_cnt + (int)(t & 1ull), __popcll(m));
+            if (lane == 0) base = __hip_atomic_fetch_add(G(P->done_cnt) + (int)(t & 1ull), __popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             base = __shfl(base, 0);
-            if (live && done) done_idx_out[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+            if (live && done) G(done_idx_out)[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
         }
     }
     // Every step launch arms the counter of the NEXT vec step, whether or not this one compacts: listed and unlisted
     // steps (hlx_step without done_idx, hlx_rollout, the fused rollout) may interleave freely.
-    if (MODE == 0 && !PERSIST && blockIdx.x == 0 && lane == 0) P->done_cnt[(int)((t + 1ull) & 1ull)] = 0;
+    if (MODE == 0 && !PERSIST && blockIdx.x == 0 && lane == 0) G(P->done_cnt)[(int)((t + 1ull) & 1ull)] = 0;
 
     // -------------------------------------------------------------------------- observation tile -> [N][26]
     if (obs_out) {
@@ -1448,7 +1482,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         WAVE_LDS_SYNC();   // the tile is rewritten by the next step
     }
     }   // step loop
-    if (PERSIST && blockIdx.x == 0 && lane == 0) { P->done_cnt[0] = 0; P->done_cnt[1] = 0; }   // nothing was listed in this launch
+    if (PERSIST && blockIdx.x == 0 && lane == 0) { G(P->done_cnt)[0] = 0; G(P->done_cnt)[1] = 0; }   // nothing was listed in this launch
     if (PERSIST && live) {   // state back to the arena, once
         STG(G_IPOS, g_ipos); STG(G_IVEL, g_ivel); STG(G_QUAT, g_quat); STG(G_MPOS, g_mpos); STG(G_MVEL, g_mvel);
         STG(G_W0, g_w0); STG(G_W1, g_w1);

@@ -119,7 +119,21 @@ def check(text):
                     op = "HOT_LOAD"
             if op != "v_readlane_b32" and len(parts) > 1 and (op.startswith(("v_", "ds_", "scratch_", "global_", "buffer_", "flat_"))):
                 src_ops = parts[1:] if op.startswith(_STORES) or op.startswith("v_cmp") else parts[2:]
-                srcs = [r for o in src_ops for r in regs(o)]
+                if op.startswith("v_pk_") and op.endswith("f32"):
+                    # packed float32: a 64-bit source names a register PAIR, of which op_sel / op_sel_hi pick one element for
+                    # the low and one for the high result (`v[218:219] ... op_sel_hi:[0,1,1]` reads v218 twice and never v219)
+                    sel = {k: [int(x) for x in m.group(1).split(",")] for k in ("op_sel", "op_sel_hi")
+                           for m in [re.search(k + r":\[([01,]+)\]", t)] if m}
+                    srcs = []
+                    for si, o in enumerate(x for x in src_ops if not x.startswith(("op_sel", "neg_", "clamp"))):
+                        rs = regs(o)
+                        if len(rs) == 2:
+                            lo = sel.get("op_sel", [0, 0, 0])[si] if si < 3 else 0
+                            hi = sel.get("op_sel_hi", [1, 1, 1])[si] if si < 3 else 1
+                            rs = sorted({rs[lo], rs[hi]})
+                        srcs += rs
+                else:
+                    srcs = [r for o in src_ops for r in regs(o)]
                 if srcs:
                     other_readers.append((pos, parts[0], srcs))
             if op == "v_readlane_b32":

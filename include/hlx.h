@@ -203,7 +203,9 @@ int hlx_reset(hlx_env *env, const uint8_t *mask, float *obs_out, void *stream);
  * advances the clock), so that two resets with no step between them start different episodes, as the reference's moving
  * generator does.  The epoch is per handle, not per environment: shards of one job draw what the unsharded batch draws
  * as long as every shard sees the same hlx_reset calls between two steps (masked ones included -- call hlx_reset on a shard
- * even when its slice of the mask is all zero), or the caller sets the epoch itself with hlx_set_reset_epoch (16 bits). */
+ * even when its slice of the mask is all zero), or the caller sets the epoch itself with hlx_set_reset_epoch (16 bits).
+ * (Counter layout: the generator sees 56 bits of the launch's clock word -- the vec-step clock in bits 0-39, i.e. 1.1e12
+ * steps, and for reset launches the epoch in bits 40-55.) */
 int hlx_set_reset_epoch(hlx_env *env, uint32_t epoch);
 uint32_t hlx_get_reset_epoch(const hlx_env *env);
 

@@ -17,8 +17,6 @@ pytestmark = pytest.mark.gpu
 
 RTOL = 1e-5          # the bar (BASELINE.json north_star: 1e-5 relative fp32), for state, reward, distance AND observation:
 OBS_ATOL = 1e-5      # an observation entry x is compared as |x - ref| <= 1e-5 * max(1, |ref|)   (|obs| <= 2)
-LOS_ILL_ATOL = 1.5e-4   # los_frame entries 2, 3, 5 where the reference's own formula is ill-conditioned (_obs_tolerance): as measured
-                        # (tools/soak_oracle.py worst 1.33e-4), not the 5e-4 of round 2
 
 
 def _obs_err(a, b):
@@ -51,26 +49,12 @@ def _check_reward_errors(errs, rc, what, resynced=False):
 
 
 def _obs_tolerance(rc, ora, done):
-    """Per-entry absolute tolerance [n, 26].  OBS_ATOL everywhere, except where the reference's own formula is
-    ill-conditioned: in `los_frame` mode the lead-angle cosine obs[5] is the direction of the Kalman velocity estimate
-    (core.py:861-868), which the reference obtains as `(kf_vel - int_vel) + int_vel` -- one float32 ulp of the
-    interceptor's speed (4e-6 m/s) is a 1e-4 relative change of a 0.04 m/s estimate --, and the LOS rates obs[2:4]
-    divide by the filtered range (core.py:810-811), which is under a metre when the filter was initialised from an empty
-    delay-line sample.  Any implementation that does not replay OpenBLAS's sgemm rounding order inside the filter lands
-    within these bounds of the reference, not within 2e-5; the bound is widened only in that regime."""
-    tol = np.full((ora.n, 26), OBS_ATOL)
-    if rc.obs_mode != 2:
-        return tol
-    so = np.frombuffer(ora.state, dtype=np.dtype(type(ora.state[0])))
-    kf = so["kf_x"]
-    tv = np.linalg.norm(kf[:, 3:6], axis=1)
-    rng = np.linalg.norm(kf[:, 0:3] - so["int_pos"], axis=1)
-    loose5 = done | (tv < 2.0)
-    loose23 = done | (rng < 100.0)
-    tol[loose5, 5] = LOS_ILL_ATOL
-    tol[loose23, 2] = LOS_ILL_ATOL
-    tol[loose23, 3] = LOS_ILL_ATOL
-    return tol
+    """Per-entry tolerance [n, 26]: the bar, everywhere.  (Round 2 widened three `los_frame` entries -- the LOS rates obs[2:4] and
+    the lead-angle cosine obs[5] -- to 5e-4 where the filtered range is under 100 m or the velocity estimate under 2 m/s: the
+    fast float32 formulas lose digits there.  The kernel now replays the reference's own arithmetic in that regime, in the
+    reference's dtype (hlx_device.h los_exact32 / los_exact64), and the Kalman covariance follows OpenBLAS's sgemm order, so
+    the exception is gone.)"""
+    return np.full((ora.n, 26), OBS_ATOL)
 
 
 def _oracle_to_gpu_state(ora, env):
@@ -351,7 +335,12 @@ def test_gpu_matches_oracle_free_running(scenario, physics, over, variant, late)
         term_obs = info["terminal_observation"].cpu().numpy()
         step_obs_g = np.where(done[:, None], term_obs, obs_h)
         step_obs_o = np.where(done[:, None], ora.terminal_obs, out["obs"])
-        eo = np.max(_obs_err(step_obs_g, step_obs_o) * (OBS_ATOL / _obs_tolerance(rc, ora, done)), axis=1)
+        eo_all = _obs_err(step_obs_g, step_obs_o) * (OBS_ATOL / _obs_tolerance(rc, ora, done))
+        eo = np.max(eo_all, axis=1)
+        if eo.max() > worst.get("obs_max_any", 0.0):
+            i_w, k_w = np.unravel_index(np.argmax(eo_all), eo_all.shape)
+            worst["obs_max_any"] = float(eo.max())
+            worst["obs_worst_at"] = f"t={t} env={i_w} entry={k_w} gpu={step_obs_g[i_w, k_w]!r} oracle={step_obs_o[i_w, k_w]!r} done={bool(done[i_w])}"
         er = _rel(rew.cpu().numpy(), out["reward"])
         ed = _rel(info["distance"].cpu().numpy(), out["distance"])
         # an env whose observation jumps (a detection decided differently at a float32 boundary) is retired

@@ -75,3 +75,15 @@ def test_kernarg_tail_load_sits_at_kernel_entry_in_every_instantiation():
     assert list(hotcheck.tail_load_positions(early).values()) == [2]
     pos = hotcheck.tail_load_positions(hotcheck.listing(build.build()))
     assert len(pos) >= 20 and all(v is not None and v <= hotcheck.TAIL_LOAD_LIMIT for v in pos.values()), pos
+
+
+def test_packed_float32_operands_read_only_the_selected_half_of_a_register_pair():
+    """`v_pk_fma_f32 v[108:109], v[218:219], ... op_sel_hi:[0,1,1]` broadcasts v218 and never reads v219: a hot word that happens
+    to be the unread half of such a pair is not a leak (seen in the generic fused-rollout kernel); the read half is."""
+    base = SPILLED.replace("\tscratch_load_dword v5, off, off offset:4\n", "").replace("\tv_mov_b32_e32 v5, 0\n", "") \
+                  .replace("\tscratch_store_dword off, v5, off offset:4\n", "")
+    unread = base.replace("\tv_readlane_b32 s1, v5, 7\n", "\tv_pk_fma_f32 v[8:9], v[4:5], v[10:11], v[12:13] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\tv_readlane_b32 s1, v5, 7\n")
+    assert not hotcheck.check(unread)[1]
+    read = unread.replace("op_sel_hi:[0,1,1]", "op_sel_hi:[1,1,1]")
+    fail = hotcheck.check(read)[1]
+    assert len(fail) == 1 and fail[0][1] == "v5"

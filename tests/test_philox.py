@@ -33,8 +33,8 @@ def test_device_uniforms_are_philox4x32_10_words():
     for for_reset in (False, True):
         sn, rn = (x.cpu().numpy() for x in env.fill_noise(for_reset=for_reset))
         t = int(env._lib.hlx_vec_steps(env._h)) + (0 if for_reset else 1)
-        if for_reset:
-            t |= 1 << 48     # explicit resets carry the reset epoch (hlx_reset calls so far: one) in bits 48-55 of the counter word
+        # explicit resets carry the 16-bit reset epoch in bits 40-55 of the counter word: the number of hlx_reset calls at the
+        # CURRENT clock value -- zero here, a step has advanced the clock since the reset above (include/hlx.h)
         for i in (0, 1, 63, 64, 129):
             gid = offset + i
 
@@ -45,4 +45,11 @@ def test_device_uniforms_are_philox4x32_10_words():
             assert [sn[11, i], sn[12, i], sn[19, i], sn[6, i]] == [u01(w) for w in x], (for_reset, i)
             r0, r1, r2 = words(8), words(9), words(10)     # RS_RESET_U0..2: the ten spawn uniforms
             assert list(rn[0:10, i]) == [u01(w) for w in (*r0, *r1, *r2[:2])], (for_reset, i)
+    # ... and a reset with no step in between: epoch 1 at the same clock value
+    env.reset()
+    sn, rn = (x.cpu().numpy() for x in env.fill_noise(for_reset=True))
+    t = int(env._lib.hlx_vec_steps(env._h)) | (1 << 40)
+    gid = offset
+    r0 = philox4x32((gid & 0xFFFFFFFF, gid >> 32, t & 0xFFFFFFFF, ((t >> 32) << 8) | 8), key)
+    assert list(rn[0:4, 0]) == [u01(w) for w in r0]
     env.close()

@@ -507,7 +507,7 @@ def test_rollout_contract_form_issues_exactly_the_hlx_step_launch(physics, volle
             assert torch.equal(a_env.terminal_obs[done], b_env.terminal_obs[done]), t
             for k in ("episode_return", "episode_length"):
                 assert torch.equal(a_env.info[k][done], b_env.info[k][done]), (t, k)
-    assert seen_done > 3 * n
+    assert seen_done >= 3 * n
     assert bytes(a_env.get_state()) == bytes(b_env.get_state())
     # ... and without the outputs the rollout is the single-pass form again: same observations, rewards, flags, state
     b_env.set_rollout_contract(False)

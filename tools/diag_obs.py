@@ -29,11 +29,15 @@ for t in range(T):
     oo = np.where(done[:, None], ora.terminal_obs, out["obs"])
     e = np.abs(og - oo)
     worst = np.maximum(worst, e.max(axis=0))
-    bad = np.argwhere(e > 2e-5)
+    bad = np.argwhere(e > 1e-5 * np.maximum(1.0, np.abs(oo)))
     for i, k in bad[:3]:
         if shown < 15:
             shown += 1
             so = np.frombuffer(ora.state, dtype=np.dtype(orc.OrcState))[i]
             print(f"t={t} env={i} obs[{k}] gpu={og[i,k]!r} orc={oo[i,k]!r} | obs gpu {og[i,:17]} | kf_x={so['kf_x']} int_pos={so['int_pos']} int_vel={so['int_vel']} steps={so['steps']} kf64={so['kf_x_is64']}")
+            sg = np.frombuffer(env.get_state(), dtype=np.dtype(type(env.get_state()[0])))[i]
+            print(f"      gpu state: kf_x={sg['kf_x']} (bits equal: {bool((sg['kf_x'].view(np.uint64) == so['kf_x'].view(np.uint64)).all())}) kf64={sg['kf_x_is64']} kf_init={sg['kf_init']} "
+                  f"int_pos equal {bool((sg['int_pos'] == so['int_pos']).all())} int_vel equal {bool((sg['int_vel'] == so['int_vel']).all())} done={bool(done[i])}")
+            print(f"      obs orc {oo[i,:17]}")
 print("worst per index:", np.array2string(worst, precision=2))
 env.close()
