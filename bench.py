@@ -52,7 +52,8 @@ BYTES_PER_ENV_STEP = {"base": 508, "v2dr": 604}     # SURVEY.md 8(d) algorithmic
 #                 the done list are written for finished environments only, ~0.2 B per env-step: not counted.)
 #   single_pass,  no info plane at all: the 8 B of info{distance, min_distance} are not stored, so they are not counted
 #   terminal_obs_only
-FORM_BYTES_DELTA = {"contract": 42, "single_pass": -8, "terminal_obs_only": -8}
+FORM_BYTES_DELTA = {"contract": 42, "single_pass": -8, "terminal_obs_only": -8,
+                    "contract_no_done_list": 42}      # (diagnostic: what the compacted done list costs on top of the info planes)
 PREROLL = 2000                                      # launches of the same form ahead of every measurement, no host sync behind them
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # The reference's own Python step cannot travel to the GPU box; its numbers were taken in the build container
@@ -414,6 +415,8 @@ def main():
     def set_form(form):
         if form == "contract":                 # what HlynrVecEnv.step_torch / step_async issue
             env.set_rollout_contract(True, done_list=True)
+        elif form == "contract_no_done_list":
+            env.set_rollout_contract(True, done_list=False)
         elif form == "terminal_obs_only":
             env.set_rollout_contract(False)
             env.set_rollout_terminal_obs(True)

@@ -55,6 +55,9 @@ namespace {
 #define HLX_INFO_RARE 0
 #endif
 #define INFO_WANTED(x) (HLX_INFO_RARE ? RARE(x) : (x))
+#ifndef HLX_INFO_FAST
+#define HLX_INFO_FAST 1
+#endif
 // Pointers that reach the kernel through the hot block (optional outputs) or through *P are GENERIC to the compiler, and a
 // generic access is a FLAT instruction: it counts in vmcnt AND lgkmcnt, may complete out of order with the global ones, and while
 // one may be pending every later `s_waitcnt vmcnt(n)` the compiler emits becomes vmcnt(0) -- on every path, taken or not.  (Found
@@ -772,6 +775,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             term_out[i] = terminated ? 1 : 0;
             trunc_out[i] = truncated ? 1 : 0;
             if (INFO_WANTED(slots & (1u << 20))) {   // some hlx_info_soa plane is wanted (one SGPR test instead of nine pointer fetches)
+#if HLX_INFO_FAST
+            if (slots & (1u << 21)) {
+                // The contract form (every plane a VecEnv facade passes, hlx_host.inc ring_slots): no null tests, and buffer stores off
+                // scalar bases -- the plane's address stays in SGPRs and all dword planes share ONE 32-bit lane offset, where the
+                // generic form below spends ~12 instructions per plane on a null test, two v_mov and a 64-bit add (round 3: the block
+                // was 110 instructions of every wave of the headline launch).
+                const uint32_t o4 = (uint32_t)i * 4u, plane = (uint32_t)n * 4u;
+#define INFO_RS(p) __builtin_amdgcn_make_buffer_rsrc((void*)(p), 0, 0x7FFFFFFF, 0x00020000)
+#define INFO_ST32(p, soff, val) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), INFO_RS(p), o4, (soff), 0)
+                INFO_ST32(HOT(opt.info.distance), 0u, distance);
+                INFO_ST32(HOT(opt.info.min_distance), 0u, min_distance);
+                INFO_ST32(HOT(opt.info.fuel), 0u, fuel);
+                INFO_ST32(HOT(opt.info.fuel_used), 0u, (steps == 1) ? fuel_step : fuel_used_prev + fuel_step);   // :886
+                {
+                    const __amdgpu_buffer_rsrc_t ri = INFO_RS(HOT(opt.info.interceptor_pos)), rm = INFO_RS(HOT(opt.info.missile_pos));   // :836-838
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ipos.x), ri, o4, 0u, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ipos.y), ri, o4, plane, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ipos.z), ri, o4, 2u * plane, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mpos.x), rm, o4, 0u, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mpos.y), rm, o4, plane, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mpos.z), rm, o4, 2u * plane, 0);
+                }
+                __builtin_amdgcn_raw_buffer_store_b32((uint32_t)steps, INFO_RS(HOT(opt.info.steps)), o4, 0u, 0);
+                {                                                                     // :846-847
+                    int remaining = intercepted ? 0 : 1, got = intercepted ? 1 : 0;
+                    if (HAS(HLX_F_VOLLEY)) {
+                        remaining = 0; got = n_int;
+#pragma unroll
+                        for (int k = 0; k < HLX_MAX_VOLLEY; ++k) remaining += (k < VK && vact[k]) ? 1 : 0;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(got | (remaining << 4)), INFO_RS(HOT(opt.info.missiles)), (uint32_t)i, 0u, 0);
+                }
+                if (HAS(HLX_F_VOLLEY) && HOT(opt.info.missile_min_distances)) {       // :848
+                    const __amdgpu_buffer_rsrc_t rv = INFO_RS(HOT(opt.info.missile_min_distances));
+#pragma unroll
+                    for (int k = 0; k < HLX_MAX_VOLLEY; ++k) if (k < VK) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vmin[k]), rv, o4, (uint32_t)k * plane, 0);
+                }
+#undef INFO_ST32
+#undef INFO_RS
+            }
+            if (RARE(!(slots & (1u << 21)))) {     // (an `if` of its own behind RARE(), not an `else`: the block then sits out of line)
+#endif
             if (HOT(opt.info.distance)) G(HOT(opt.info.distance))[i] = distance;
             if (HOT(opt.info.min_distance)) G(HOT(opt.info.min_distance))[i] = min_distance;
             if (HOT(opt.info.fuel)) G(HOT(opt.info.fuel))[i] = fuel;
@@ -800,6 +845,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
 #pragma unroll
                 for (int k = 0; k < HLX_MAX_VOLLEY; ++k) if (k < VK) md[(size_t)k * (size_t)n] = vmin[k];
             }
+#if HLX_INFO_FAST
+            }
+#endif
             }
         }
 #undef PIN4

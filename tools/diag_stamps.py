@@ -33,6 +33,12 @@ if steady:      # desynchronise the episodes first (fused rollout), then time si
     for _ in range(64):
         env.rollout_torch(tape, 2)
     env.set_rollout_fused(1)
+form = os.environ.get("HLX_STAMP_FORM", "single_pass")     # contract = what step_torch issues: terminal observations + info planes + done list
+if form == "contract":
+    env.set_rollout_contract(True, done_list=True)
+elif form == "terminal_obs_only":
+    env.set_rollout_terminal_obs(True)
+print("form:", form)
 for t in range(60):
     env.rollout_torch(tape[t:t + 1], 2)
     if t >= 20:
