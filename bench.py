@@ -242,14 +242,15 @@ class SelfCheck:
                 "state_max_rel": state_max, "against": "oracle/hlx_oracle.c fed the exported Philox draws (hlx_fill_noise)"}
 
 
-def measured_traffic(physics, n):
+def measured_traffic(physics, n, form="single_pass"):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE in
     separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  STATIC: read from the committed
     file, not collected by this run (counters need rocprofv3 around the process); None when no measurement exists."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as f:
-            d = json.load(f).get(f"{physics}:{n}", {})
+            table = json.load(f)
+            d = table.get(f"{physics}:{n}:{form}") or table.get(f"{physics}:{n}", {})      # per form where measured (round 3: contract)
             return d.get("hbm_bytes_per_launch"), "static: profiles/hbm_traffic.json (%s)" % d.get("source", "rocprofv3 --pmc, committed")
     except OSError:
         return None, None
@@ -535,7 +536,7 @@ def main():
         cpu = cpu_baseline(rc)
 
     if rank == 0:
-        traffic, traffic_src = measured_traffic(args.physics, n)
+        traffic, traffic_src = measured_traffic(args.physics, n, forms[0])
         roof = {"bound": "hbm", "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
                 "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "hlx_env_kernel<%s, step>" % variant, "form": forms[0],
