@@ -13,6 +13,8 @@
  * in double and rounded once are correctly rounded (53 >= 2*24+2), so this reproduces float32
  * arithmetic exactly.  np.dot/np.linalg.norm on float32 3-vectors = float32 products accumulated
  * in double, rounded once (OpenBLAS sdot as shipped with numpy 2.2.6; measured).
+ * float32 matrix products (the Kalman predict's F @ P @ F.T) = OpenBLAS sgemm: one fused multiply-add
+ * chain per element, k ascending (measured here, kf_predict below); matrix-vector products do not fuse.
  *
  * All file:line citations are to /root/reference/rl_system/.
  */
