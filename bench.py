@@ -491,35 +491,21 @@ def main():
                  "note": "same K steps through hlx_rollout with hlx_set_rollout_fused: state stays in registers for "
                          "steps_per_launch steps, bit-identical results; not the headline (a policy in the loop needs one launch per step)"}
 
-    # config 3 and a batch whose state (2.6 GB) defeats the 256 MB Infinity Cache: contract form, wall clock
+    # config 3 and a batch whose state (2.6 GB) defeats the 256 MB Infinity Cache -- each in a FRESH process
+    # (tools/extra_point.py: at HBM-bound sizes the step's time depends on the process's whole allocation history)
     extra = None
     if not args.no_extra_points and world == 1:
         extra = []
         env.close()
+        torch.cuda.empty_cache()
         for phys, n_x, k_x, d_x in (("v2dr", ENVS_PER_GPU, 1000, 4096), ("base", 4 * 1024 * 1024, 60, 0)):
-            rc_x = resolve_config(scenario_config("medium", phys))
-            env = HlynrVecEnv(resolved=rc_x, num_envs=n_x, device=local_rank, seed=seed)
-            tape_x = torch.rand((min(k_x, 256), n_x, 6), generator=gen, device=dev, dtype=torch.float32) * 2.0 - 1.0
-            env.reset_torch()
-            if d_x:
-                env.set_rollout_fused(64)
-                for _ in range(d_x // tape_x.shape[0]):
-                    env.rollout_torch(tape_x, out_slots)
-                env.set_rollout_fused(1)
-            env.set_rollout_contract(True, done_list=True)
-            env.rollout_torch(tape_x[:max(1, k_x // 4)], out_slots)
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for lo, hi in tape_schedule(k_x, tape_x.shape[0]):
-                env.rollout_torch(tape_x[lo:hi], out_slots)
-            torch.cuda.synchronize(dev)
-            dt = time.perf_counter() - t0
-            b = BYTES_PER_ENV_STEP[phys] + FORM_BYTES_DELTA["contract"]
-            extra.append({"workload": f"medium scenario, {phys} physics, {n_x} envs/GPU", "form": "contract", "value": n_x * k_x / dt, "unit": "env-steps/s",
-                          "us_per_step": 1e6 * dt / k_x, "algorithmic_bytes_per_env_step": b, "desync_steps": d_x,
-                          "roofline_frac": n_x * k_x * b / dt / 1e9 / HBM_PEAK_GBS})
-            env.close()
-            del tape_x
+            cmd = [sys.executable, os.path.join(ROOT, "tools", "extra_point.py"), phys, str(n_x), str(k_x), str(d_x)]
+            try:
+                res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, LOCAL_RANK=str(local_rank)))
+                lines = [ln for ln in res.stdout.splitlines() if ln.startswith("[")]
+                extra += json.loads(lines[-1]) if res.returncode == 0 and lines else [{"workload": f"{phys} {n_x}", "error": (res.stderr or res.stdout)[-400:]}]
+            except (subprocess.TimeoutExpired, OSError, ValueError) as exc:
+                extra.append({"workload": f"{phys} {n_x}", "error": repr(exc)[:400]})
 
     # ---------------------------------------------------------------- self-check (rank 0; every collective is behind us)
     selfcheck = None
