@@ -122,6 +122,7 @@ SYMBOLS = {
     "hlx_obs_next_slot": (_P, [_P]),
     "hlx_obs_push_reset": (C.c_int, [_P, _P, _P]),
     "hlx_obs_push": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "hlx_obs_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(HlxInfoSoa), _P, _P, _P, _P]),
     "hlx_obs_emit": (C.c_int, [_P, i32, _P, _P]),
     "hlx_obs_set_mode": (C.c_int, [_P, i32, i32, i32]),
     "hlx_obs_get_stats": (C.c_int, [_P, _P, _P, _P]),

@@ -309,6 +309,15 @@ class HlynrVecEnv(_SB3VecEnv):
 
         Returns (obs, reward, terminated, truncated, info) - all torch tensors living on the GPU; they are
         overwritten by the next call (clone what must survive)."""
+        actions, di, nd = self._step_args(actions, want_done_list)
+        _lib.check(self._lib.hlx_step(self._h, actions.data_ptr(), obs_ptr if obs_ptr is not None else self.obs.data_ptr(),
+                                      self.reward.data_ptr(),
+                                      self.terminated.data_ptr(), self.truncated.data_ptr(),
+                                      self.terminal_obs.data_ptr(), di, nd, C.byref(self._info_soa), self._stream()))
+        return self.obs, self.reward, self.terminated, self.truncated, self._step_info(want_done_list)
+
+    def _step_args(self, actions, want_done_list):
+        """Validated action tensor + the done-list pointers of the step about to be issued (also used by wrappers.py)."""
         t = self._torch
         if actions.dtype != t.float32 or not actions.is_contiguous() or actions.device != self.device:
             actions = actions.to(device=self.device, dtype=t.float32).contiguous()
@@ -318,15 +327,14 @@ class HlynrVecEnv(_SB3VecEnv):
         self.n_done = self._n_done2[(int(self._lib.hlx_vec_steps(self._h)) + 1) & 1:][:1]
         di = self.done_idx.data_ptr() if want_done_list else None
         nd = self.n_done.data_ptr() if want_done_list else None
-        _lib.check(self._lib.hlx_step(self._h, actions.data_ptr(), obs_ptr if obs_ptr is not None else self.obs.data_ptr(),
-                                      self.reward.data_ptr(),
-                                      self.terminated.data_ptr(), self.truncated.data_ptr(),
-                                      self.terminal_obs.data_ptr(), di, nd, C.byref(self._info_soa), self._stream()))
+        return actions, di, nd
+
+    def _step_info(self, want_done_list):
         info = dict(self.info)
         info["terminal_observation"] = self.terminal_obs
         if want_done_list:
             info["done_idx"], info["n_done"] = self.done_idx, self.n_done
-        return self.obs, self.reward, self.terminated, self.truncated, info
+        return info
 
     def rollout_torch(self, action_tape, out_slots: int = 1):
         """T steps from a pre-supplied tape [T, N, 6] with one launch per step issued from C

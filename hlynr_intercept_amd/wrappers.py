@@ -220,10 +220,14 @@ class _DeviceObsWrapper(_SB3VecEnv):
         """(stacked obs [N, n_stack*26], reward, terminated, truncated, info); info['terminal_observation'] holds the
         stacked (and normalised) terminal observation in the rows of finished environments."""
         b = self._base
-        _, rew, term, trunc, info = b.step_torch(actions, want_done_list, obs_ptr=self._lib.hlx_obs_next_slot(self._p))
-        _lib.check(self._lib.hlx_obs_push(self._p, term.data_ptr(), trunc.data_ptr(), b.terminal_obs.data_ptr(), rew.data_ptr(),
-                                          self.stacked.data_ptr(), self.terminal_stacked.data_ptr(), self.reward_out.data_ptr(),
-                                          b._stream()))
+        # one FFI crossing per training step: hlx_obs_step issues the step launch (the new frame goes straight into the
+        # pipeline's frame ring) and the pipeline's launches behind it
+        actions, di, nd = b._step_args(actions, want_done_list)
+        rew, term, trunc = b.reward, b.terminated, b.truncated
+        _lib.check(self._lib.hlx_obs_step(self._p, b._h, actions.data_ptr(), rew.data_ptr(), term.data_ptr(), trunc.data_ptr(),
+                                          b.terminal_obs.data_ptr(), di, nd, C.byref(b._info_soa), self.stacked.data_ptr(),
+                                          self.terminal_stacked.data_ptr(), self.reward_out.data_ptr(), b._stream()))
+        info = b._step_info(want_done_list)
         info = dict(info)
         info["terminal_observation"] = self.terminal_stacked
         info["original_reward"] = rew

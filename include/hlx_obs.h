@@ -74,6 +74,18 @@ int hlx_obs_push(hlx_obs *p, const uint8_t *terminated, const uint8_t *truncated
                  const float *reward, float *stacked_out, float *terminal_stacked_out, float *reward_out,
                  void *stream);
 
+/* hlx_step + hlx_obs_push in ONE call (what `VecNormalize(VecFrameStack(envs)).step_wait()` does on top of the reference's
+ * env.step, train_flat_ppo.py:384-399): the step kernel writes the new frame into hlx_obs_next_slot() and the pipeline's
+ * launches follow on the same stream, so that a Python caller crosses the FFI once per training step instead of three
+ * times.  `env` is the hlx_env (hlx.h) whose observations the pipeline stacks; reward / terminated / truncated /
+ * terminal_obs [N][D] are the step's raw outputs (required), done_idx / n_done / info as for hlx_step (optional);
+ * stacked_out, terminal_stacked_out, reward_out as for hlx_obs_push. */
+struct hlx_env;
+struct hlx_info_soa;
+int hlx_obs_step(hlx_obs *p, struct hlx_env *env, const float *actions, float *reward, uint8_t *terminated, uint8_t *truncated,
+                 float *terminal_obs, int32_t *done_idx, int32_t *n_done, const struct hlx_info_soa *info, float *stacked_out,
+                 float *terminal_stacked_out, float *reward_out, void *stream);
+
 /* Re-emit the current stacks without advancing anything: normalise = 0 gives VecNormalize.get_original_obs(). */
 int hlx_obs_emit(hlx_obs *p, int32_t normalise, float *stacked_out, void *stream);
 
