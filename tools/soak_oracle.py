@@ -34,7 +34,7 @@ for scenario, physics, over in (CASES if not ONLY else [CASES[int(k)] for k in O
     sn, rn = env.fill_noise(for_reset=True)
     env.reset_torch()
     ora.reset(rn.cpu().numpy().T.copy())
-    bad = dict(reward=0, distance=0, flags=0)
+    bad = dict(reward=0, distance=0, flags=0, fuel_used=0)
     worst_obs, n_done, t0 = np.zeros(26), 0, time.time()
     for t in range(T):
         a = torch.rand((n, 6), generator=g, device=env.device) * 2 - 1
@@ -49,6 +49,7 @@ for scenario, physics, over in (CASES if not ONLY else [CASES[int(k)] for k in O
         bad["flags"] += int(((te != out["terminated"]) | (tr != out["truncated"]) | ((info["flags"].cpu().numpy() & 1) != out["intercepted"])).sum())
         bad["reward"] += int((rew.cpu().numpy().astype(np.float64) != out["reward"].astype(np.float32).astype(np.float64)).sum())
         bad["distance"] += int((info["distance"].cpu().numpy() != out["distance"]).sum())
+        bad["fuel_used"] += int((info["fuel_used"].cpu().numpy() != out["fuel_used"]).sum())
         og = np.where(done[:, None], info["terminal_observation"].cpu().numpy(), obs.cpu().numpy())
         oo = np.where(done[:, None], ora.terminal_obs, out["obs"])
         worst_obs = np.maximum(worst_obs, np.abs(og - oo).max(axis=0))
