@@ -60,6 +60,14 @@ struct KOpt {              // optional caller buffers (re-uploaded only when the
     const double* step_noise;    // parity mode: slot-major [HLX_STEP_SLOTS][N] float64 unit draws (NULL = Philox)
     const double* reset_noise;   // [HLX_RESET_SLOTS][N]
     const uint8_t* reset_mask;
+    // observation pipeline riding on the step (hlx_obs_step, include/hlx_obs.h): the step kernel leaves, per 64-environment block,
+    // the float64 column sums / sums of squares of the NEWEST frame (its own observation tile) and advances the discounted returns,
+    // so that the pipeline's moments pass over the batch disappears.  NULL = no pipeline attached to this launch.
+    double* pipe_partial;        // [blocks][pipe_stride]: column c of the stacked batch at [2 c], [2 c + 1]; return sums at [stride - 4],
+                                 // [stride - 3]; the block's done mask (64-bit ballot, as a bit pattern) at [stride - 2]
+    double* pipe_returns;        // [N] discounted returns (NULL: not updated this step)
+    double pipe_gamma;
+    int32_t pipe_stride, pipe_col0;   // 2 F + 4 doubles per block; first column of the newest frame, (n_stack - 1) * D
 };
 struct KCur {              // curriculum scalars in force (re-uploaded when hlx_set_global_step changes them)
     double half_beam;

@@ -209,6 +209,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
     float* row = tile + lane * HLX_OBS_DIM;
     bool done = false;
     int32_t* done_idx_out = nullptr;   // optional compaction output (read from the hot block inside the live section)
+    float pipe_reward = 0.f;           // this step's reward, for the observation pipeline's discounted returns (bit 22 of `slots`)
+    double pipe_ret_prev = 0.;
 
 #ifdef HLX_STAMPS
     unsigned long long* stamp_base = P->stamps + (size_t)blockIdx.x * 16;   // fetched once: a per-stamp scalar load
@@ -397,6 +399,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         // soon as the hot words can be read, and is first needed in the info block a whole physics section later
         float fuel_used_prev = 0.f;
         if (MODE == 0 && INFO_WANTED(slots & (1u << 20)) && HOT(opt.info.fuel_used)) fuel_used_prev = G(HOT(opt.info.fuel_used))[ic];
+        // (the same for the observation pipeline's discounted returns, when one rides on this launch)
+        if (MODE == 0 && !PERSIST && RARE(slots & (1u << 22)) && HOT(opt.pipe_returns)) pipe_ret_prev = G(HOT(opt.pipe_returns))[ic];
         if (live) {   // ============================== per-environment work, live lanes only ==============================
         STAMP(2);   // Philox block done (loads still in flight)
         V3 ipos = v3(g_ipos.x, g_ipos.y, g_ipos.z), ivel = v3(g_ivel.x, g_ivel.y, g_ivel.z);
@@ -755,6 +759,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             }
             done = terminated || truncated;
             ep_return += reward;
+            pipe_reward = reward;
         } else {
             // reset-only launch: `done` marks the envs to reset
             done = HOT(opt.reset_mask) ? (G(HOT(opt.reset_mask))[i] != 0) : true;
@@ -1498,6 +1503,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         WAVE_LDS_SYNC();
         const int rows = min(64, n - blockIdx.x * 64);
         float* dst = obs_out + (size_t)blockIdx.x * 64 * HLX_OBS_DIM;
+        if (MODE == 0 && !PERSIST && RARE(slots & (1u << 22))) {
+            // The observation pipeline rides on this launch (hlx_obs_step): this block's partial sums of what VecNormalize reduces
+            // over the batch -- the float64 column sums / sums of squares of the NEWEST frame, which is the tile in LDS right now
+            // (rows of finished lanes hold the first observation of their new episode, exactly the frame the pipeline stacks),
+            // and of the discounted returns (VecNormalize._update_reward: returns = returns * gamma + reward).  Fixed summation
+            // order, no atomics: the pipeline's finalize kernel adds the blocks' partials in block order.
+            double* const out = HOT(opt.pipe_partial) + (size_t)blockIdx.x * (size_t)HOT(opt.pipe_stride);
+            const int c = lane & 31, half = lane >> 5;                  // lanes 0-25: rows 0-31 of column c; lanes 32-57: rows 32-63
+            double cs = 0., cq = 0.;
+            if (c < HLX_OBS_DIM) {
+                const int r_end = min(32 * half + 32, rows);
+#pragma unroll 8
+                for (int r = 32 * half; r < r_end; ++r) {
+                    const double x = (double)tile[r * HLX_OBS_DIM + c];
+                    cs += x; cq += x * x;
+                }
+            }
+            cs += __shfl_down(cs, 32); cq += __shfl_down(cq, 32);
+            if (lane < HLX_OBS_DIM) {
+                G(out)[2 * (HOT(opt.pipe_col0) + lane)] = cs;
+                G(out)[2 * (HOT(opt.pipe_col0) + lane) + 1] = cq;
+            }
+            double rs = 0., rq = 0.;
+            if (HOT(opt.pipe_returns)) {
+                if (live) {
+                    const double ret = pipe_ret_prev * HOT(opt.pipe_gamma) + (double)pipe_reward;
+                    G(HOT(opt.pipe_returns))[i] = ret;
+                    rs = ret; rq = ret * ret;
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { rs += __shfl_down(rs, off); rq += __shfl_down(rq, off); }
+            }
+            const unsigned long long fin = __ballot(live && done);        // who finished: the finalize kernel subtracts their older frames
+            if (lane == 0) {
+                G(out)[HOT(opt.pipe_stride) - 4] = rs; G(out)[HOT(opt.pipe_stride) - 3] = rq;
+                G(out)[HOT(opt.pipe_stride) - 2] = __longlong_as_double((long long)fin);
+            }
+        }
         if (MODE == 0) {
             if (rows == 64) {
                 const float4* src4 = reinterpret_cast<const float4*>(tile);

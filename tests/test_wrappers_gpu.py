@@ -178,7 +178,9 @@ def test_incremental_moments_equal_the_full_reduction(n, n_stack):
         finally:
             os.environ.pop("HLX_OBS_FULL_MOMENTS", None)
     for (m0, v0, c0, r0), (m1, v1, c1, r1) in zip(stats[False], stats[True]):
-        assert c0 == c1 and r0 == r1
+        # (the return sums: identical order in the incremental and the full kernel; one more order since round 3, when the step
+        # kernel forms them per 64-environment block -- float64 rounding apart)
+        assert c0 == c1 and abs(r0 - r1) <= 1e-13 * max(1.0, abs(r1))
         assert np.max(np.abs(m0 - m1)) <= 1e-12 * max(1.0, np.max(np.abs(m1)))
         assert np.max(np.abs(v0 - v1)) <= 1e-11 * max(1.0, np.max(np.abs(v1)))
     assert stats[False][-1][2] > n * 70      # the statistics did advance
