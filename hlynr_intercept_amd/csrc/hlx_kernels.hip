@@ -879,8 +879,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         // lane of the wave finished): the common step falls out of the loop without a taken branch.
         int pass = (MODE == 0 ? 0 : 1);
         bool again;
-#pragma unroll 1
-        do {
+        // One trip through the observation code.  The second trip of a step launch (finished lanes respawn and are observed again:
+        // rare, out of line, and the tail of every launch that wants terminal observations) is a SPECIALISED copy: every lane it
+        // observes has just respawned -- no delayed samples, no initialised filter, no detection history -- so the Kalman update /
+        // predict, the ring reads and their selects are not compiled into it at all, where the shared loop body of rounds 1-2
+        // jumped over them one taken branch at a time.  -DHLX_FRESH_TRIP=0: the second trip as an unspecialised copy (A/B).
+#ifndef HLX_FRESH_TRIP
+#define HLX_FRESH_TRIP 1
+#endif
+        auto trip = [&](auto all_fresh_tag) __attribute__((always_inline)) {
+            constexpr bool ALLF = decltype(all_fresh_tag)::value;
             STAMP2(1);  // close-up: loop top
             bool fresh = false;      // this lane has just respawned: its observation is the first of a new episode
             // `rsalt` is an opaque zero defined inside the respawn pass: the respawn draws are pure functions of
@@ -900,7 +908,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             float n_on = u_on, n_g = u_g;
             double n_dl = u_dl;
             D3 n_gp = z_gp, n_gv = z_gv;
-            const unsigned long long dmask = (pass == 1 || single) ? __ballot(done) : 0ull;
+            const unsigned long long dmask = (ALLF || pass == 1 || single) ? __ballot(done) : 0ull;
             if (RARE(dmask != 0ull)) {
                 float rd[RS_ITEMS][4];
 #pragma unroll
@@ -1098,7 +1106,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     worsening = 0; crossed = false;
                 }
             }
-            const bool act = (pass == 0) || done;
+            const bool act = ALLF ? done : ((pass == 0) || done);
+            const bool fresh_k = ALLF ? true : fresh;      // (a compile-time `true` in the specialised second trip)
             if (act) {
                 // ======================================================== core.py:511-691 radar detection
                 STAMP2(2);  // close-up: draws selected
@@ -1135,7 +1144,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 if (HOT(c.o_delay) > 0) {                                                // :576-588 onboard delay ring
                     on_sample = make_float4(rel.x, rel.y, rel.z, on_det ? 1.f : (HAS(HLX_F_RADAR_DEBUG) ? on_why : 0.f));   // w: 1 detected, -reason otherwise
                     d_on = v3(0.f, 0.f, 0.f); d_on_det = false; on_why = -4.f;              // :582 'sensor_delay_initialization'
-                    if (!fresh && steps >= on_delay) {
+                    if (!fresh_k && steps >= on_delay) {
                         int slot = o_wslot - on_delay;                            // (t - on_delay) mod o_cap
                         slot += (slot < 0) ? o_cap : 0;
                         float4 s = oring[(size_t)slot * N + i];
@@ -1195,7 +1204,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     g_sp = g_pos; g_sq = g_q; g_sflag = g_det ? 1.f : 0.f;
                     g_s2 = make_float4(g_vel.x, g_vel.y, g_vel.z, 0.f);
                     d_gp64 = d3(0., 0., 0.); d_gv = v3(0.f, 0.f, 0.f); d_gq = 0.f; d_g_det = false; d_g64 = false;
-                    if (!fresh && steps >= HOT(c.g_delay)) {                             // sample pre-loaded at kernel entry
+                    if (!fresh_k && steps >= HOT(c.g_delay)) {                             // sample pre-loaded at kernel entry
                         const double2 s0 = gr0;
                         const float4 s1 = gr1, s2 = gr2;
                         d_gp64 = d3(s0.x, s0.y, __hiloint2double(__float_as_int(s1.y), __float_as_int(s1.x)));
@@ -1219,7 +1228,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 const float agree = 1.0f - fminf(fnorm_out(d_on - d_gp) * 0.005f, 1.0f);
                 const float f_both = clampf((float)(0.35 * HOT(c.radar_quality64)) + 0.50f * d_gq + 0.15f * agree, 0.f, 1.f);
                 const float fusion = d_g_det ? (d_on_det ? f_both : d_gq * 0.6f) : (d_on_det ? (float)(HOT(c.radar_quality64) * 0.5) : 0.f);
-                if (!fresh) {
+                if (!fresh_k) {
                     // bit 7: a delayed onboard sample exists (core.py:576-593): info['radar_quality'] is the configured quality then,
                     // detected or not, and 0.0 only while the delay line is still filling
                     det_bits = (d_on_det ? 32u : 0u) | (d_g_det ? 64u : 0u) | ((HOT(c.o_delay) == 0 || steps >= on_delay) ? 128u : 0u);
@@ -1262,7 +1271,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     // lanes agree on the dtype -- the usual case -- executes one path of plain arithmetic.
                     const D3 zw = d3((double)ipos.x + z.x, (double)ipos.y + z.y, (double)ipos.z + z.z);            // :749
                     const V3 zf = to_v3(zw);                                        // the float32 measurement (when !m64)
-                    if (RARE(!kf_init)) {                                           // core.py:93-96
+                    if (ALLF || RARE(!kf_init)) {                                   // core.py:93-96
                         kxp = to_d3(zf);
                         kxv = d3(0., 0., 0.);
                         kf_init = true;
@@ -1289,7 +1298,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     }
                     have_track = true;
                 } else {                                                            // :760-774
-                    if (kf_init) {                                                  // core.py:80-89 predict
+                    if (!ALLF && kf_init) {                                         // core.py:80-89 predict
                         if (kf_x64) {
                             const double dtf = (double)HOT(c.dt);
                             kxp = d3(kxp.x + dtf * kxv.x, kxp.y + dtf * kxv.y, kxp.z + dtf * kxv.z);
@@ -1304,7 +1313,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                         const float n_pp = __builtin_fmaf(a_pv, HOT(c.dt), a_pp), n_vp = __builtin_fmaf(p_vv, HOT(c.dt), p_vp);
                         p_pp = n_pp + HOT(c.q11); p_pv = a_pv + HOT(c.q12); p_vp = n_vp + HOT(c.q12); p_vv = p_vv + HOT(c.q22);
                     }
-                    have_track = kf_init;
+                    have_track = ALLF ? false : kf_init;
                 }
                 STAMP(11);  // measurement fusion + Kalman filter
                 // ---- observation vector: pure outputs, ordinary fast float32 from here on
@@ -1422,9 +1431,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 row[25] = fusion;                                                   // :1030
                 STAMP(12);  // 26-D observation formulas -> LDS row
             }
-            again = pass == 0 && !single && __ballot(done) != 0ull;
+            again = !ALLF && pass == 0 && !single && __ballot(done) != 0ull;
             ++pass;
-        } while (RARE(again));
+        };
+        trip(std::false_type{});
+#if HLX_FRESH_TRIP
+        if (RARE(again)) trip(std::true_type{});
+#else
+        if (RARE(again)) trip(std::false_type{});
+#endif
 
         STAMP(13);  // observation passes (incl. loop exit)
         // ---------------------------------------------------------------------- store state + rings
