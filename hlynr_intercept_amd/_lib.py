@@ -58,7 +58,7 @@ class HlxEnvState(C.Structure):
         ("int_pos", f32 * 3), ("int_vel", f32 * 3), ("int_quat", f32 * 4), ("fuel", f32),
         ("thrust_actual", f32 * 3), ("mis_pos", f32 * 3), ("mis_vel", f32 * 3),
         ("prev_distance", f32), ("min_distance", f32), ("last_distance", f32),
-        ("steps", i32), ("worsening", i32), ("crossed", i32), ("kf_init", i32), ("kf_x_is64", i32), ("pad0", i32),
+        ("steps", i32), ("worsening", i32), ("crossed", i32), ("kf_init", i32), ("kf_x_is64", i32), ("episode", i32),
         ("wind", f64 * 3), ("kf_x", f64 * 6), ("kf_P", f32 * 4),
         ("on_delay", i32), ("on_len", i32), ("on_ring", (f32 * 4) * RING_CAP),
         ("g_len", i32), ("g_ring", (f64 * 8) * RING_CAP),
@@ -104,6 +104,9 @@ SYMBOLS = {
     "hlx_get_reset_epoch": (u32, [_P]),
     "hlx_set_seed": (C.c_int, [_P, u64]),
     "hlx_selftest_math": (C.c_int, [i32, _P, f32, _P, i64, _P]),
+    "hlx_set_episode_pool": (C.c_int, [_P, i32]),
+    "hlx_get_episode_pool": (i32, [_P]),
+    "hlx_get_episode_pool_misses": (C.c_int, [_P, C.POINTER(i64)]),
     "hlx_set_load_schedule": (C.c_int, [_P, i32]),
     "hlx_get_load_schedule": (i32, [_P]),
     "hlx_profile": (C.c_int, [_P, i32]),

@@ -41,6 +41,19 @@ enum : int {
 };
 // ground ring slot: double2 {rel_pos x, y}, {double rel_pos z, float quality, float sample-was-a-detection}, float4 {rel_vel xyz, pad}
 constexpr int GROUND_RING_WORDS16 = 3;
+// Next-episode pool entry (hlx_kernels.hip, "next-episode pool"): the state groups as a respawned lane would store them, the
+// samples its first observation pushes into the two delay rings, and that observation's row.  Blocked like the arena:
+// pool[env / 64][group][env % 64].
+enum : int {
+    PG_ON = N_GROUPS,          // float4: onboard ring sample
+    PG_GR = PG_ON + 1,         // 3 x 16 bytes: ground ring sample (the ring slot's three words)
+    PG_ROW = PG_GR + GROUND_RING_WORDS16,   // 7 x float4: the 26-float observation row (last two floats unused)
+    POOL_GROUPS = PG_ROW + (HLX_OBS_DIM + 3) / 4
+};
+// bytes behind the rings in the arena allocation, for `blocks` 64-environment blocks: pool | tag u32[] | episode u32[] |
+// int32[4] counters | u64[blocks] masks of the entries used since the last fill
+constexpr int HLX_POOL_INTERVAL_DEFAULT = 64;    // step launches between two pool fills
+constexpr size_t pool_aux_words16(size_t blocks) { return blocks * 64 * POOL_GROUPS + blocks * 32 + 1 + (blocks + 1) / 2; }
 
 // ---------------------------------------------------------------------------------------------------
 // Kernel arguments.  The kernarg segment of a launch is freshly written memory: a scalar load from it misses

@@ -107,6 +107,43 @@ DEV void wt16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, float4 v) 
     u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
     __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, HLX_ST_AUX);
 }
+// (pool entries: plain per-lane stores -- a fill touches a few thousand environments)
+struct PoolPtrs {
+    size_t blocks;          // 64-environment blocks
+    float4* pool;           // [blocks][POOL_GROUPS][64]
+    uint32_t *tag, *ep_cur; // [blocks * 64] each
+    int32_t* rf_cnt;            // [4]: [2] = respawns computed inside step launches (diagnostics)
+    unsigned long long* rf_mask;   // [blocks]: the lanes of each block that have used their entry since the last fill
+};
+// the pool lives behind the rings in the arena allocation (hlx_host.inc hlx_create computes the same addresses)
+DEV PoolPtrs pool_ptrs(float4* arena, int n, int g_planes, int o_planes) {
+    PoolPtrs p;
+    p.blocks = (size_t)((n + 63) >> 6);
+    p.pool = arena + p.blocks * (N_GROUPS * 64) + ((size_t)(g_planes * GROUND_RING_WORDS16) + (size_t)o_planes) * (size_t)n;
+    p.tag = reinterpret_cast<uint32_t*>(p.pool + p.blocks * (POOL_GROUPS * 64));
+    p.ep_cur = p.tag + p.blocks * 64;
+    p.rf_cnt = reinterpret_cast<int32_t*>(p.ep_cur + p.blocks * 64);
+    p.rf_mask = reinterpret_cast<unsigned long long*>(p.rf_cnt + 4);
+    return p;
+}
+// A value whose only reader asks for it in an accumulation register (AGPR) is loaded into one and stays there: the way to keep
+// ~90 prefetched dwords out of the 256 ordinary VGPRs while a section that needs most of those runs (a wave that is alone on its
+// SIMD owns all 512 registers of a lane, but only 256 of them are addressable as ordinary VGPRs).
+DEV float acc_read(float x) {
+    float r;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(x));
+    return r;
+}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+DEV float4 pool_get(const float4* PA, int g) {
+    const f32x4 v = *(const __attribute__((address_space(1))) f32x4*)(PA + g * 64);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+DEV void pool_put(float4* PA, int g, float4 v) { *(__attribute__((address_space(1))) f32x4*)(PA + g * 64) = f32x4{v.x, v.y, v.z, v.w}; }
+DEV void pool_put(float4* PA, int g, double2 v) {
+    pool_put(PA, g, make_float4(__int_as_float(__double2loint(v.x)), __int_as_float(__double2hiint(v.x)), __int_as_float(__double2loint(v.y)),
+                                __int_as_float(__double2hiint(v.y))));
+}
 DEV void wt16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, double2 v) {
     u32x4 d = {(uint32_t)__double2loint(v.x), (uint32_t)__double2hiint(v.x), (uint32_t)__double2loint(v.y), (uint32_t)__double2hiint(v.y)};
     __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, HLX_ST_AUX);
@@ -166,23 +203,35 @@ template <int BAKE, int OFF> DEV double cold_get(const KParams* P) {
 // LATE = instantiation for small batches (<= two 64-env waves per SIMD): the Kalman groups and the delayed ring sample are
 // loaded as a second batch after the Philox block instead of at kernel entry (see below; a run-time switch was tried
 // and lost both ways -- the optimiser merges the two load sites).
-template <uint32_t SPEC, int MODE /*0 = step, 1 = reset-only*/, bool NOISE, bool PERSIST = false, bool LATE = false, int BAKE = 0>
+// MODE 2 = next-episode pool fill (see "next-episode pool" below): the respawn + first observation of the NEXT episode of
+// the listed environments, computed off the step's critical path and stored where the step kernel picks it up when the
+// environment finishes.
+// LATE = 2: the schedule for batches that give a SIMD ONE wave (<= 65 536 environments on 256 CUs): LATE = 1, and -- the wave
+// having the register file to itself -- the pool entry of a lane that has just finished is requested as soon as the step knows
+// it has (right behind the termination tests) and sits in registers while the observation pass runs, instead of being fetched
+// when the pass is over, a memory round trip on the tail of the launch.
+template <uint32_t SPEC, int MODE /*0 = step, 1 = reset-only, 2 = pool fill*/, bool NOISE, bool PERSIST = false, int LATE = 0, int BAKE = 0>
 // The parity (NOISE) and reset-only (MODE 1) instantiations never run at a size where occupancy matters: they get the
 // whole register file, hence no scratch spills (see tools/check_hot_words.py for why a spilled hot word is fatal).
 #ifndef HLX_WAVES_PER_EU
-#define HLX_WAVES_PER_EU(noise, mode) (((noise) || (mode) == 1) ? 1 : 2)
+#define HLX_WAVES_PER_EU(noise, mode, persist, late) (((noise) || (mode) != 0 || (persist) || (late) == 2) ? 1 : 2)
 #endif
-// waves_per_eu(2): keep every instantiation within 256 VGPRs so that two waves fit on a SIMD.  The single-step kernels
-// are there anyway (183); the fused-rollout ones spill 4-19 dwords to scratch for it and run 1.5x faster once the batch
-// gives a SIMD two waves (1 M envs: 107 -> 72 us per step, 1.46e10 env-steps/s), unchanged below that.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PER_EU(NOISE, MODE)))) void hlx_env_kernel(
+// waves_per_eu(2): keep the single-step kernels within 256 VGPRs so that two waves fit on a SIMD (they are there anyway: ~205).
+// The fused-rollout instantiations carry the state groups in registers on top of that and do not fit: until round 3 they were
+// held to 256 as well, spilled 30-odd dwords to scratch, and ran 1.5x faster for it once a batch gave a SIMD two waves (1 M
+// envs: 107 -> 72 us per step).  But WHICH registers the allocator spills changes with every edit of the kernel, and when it
+// picks a hot-constant register the result is wrong (hotcheck.py refuses the library): after the next-episode pool went in,
+// one fused instantiation or another failed that check whatever was rearranged.  They now get the whole register file -- no
+// scratch, nothing to refuse -- and give up the second wave per SIMD above 65 536 environments per GPU.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PER_EU(NOISE, MODE, PERSIST, LATE)))) void hlx_env_kernel(
     // ---- 14 dwords preloaded into SGPRs by the dispatcher: everything needed to issue the state, action and
     //      ring loads and to run the Philox block without waiting for memory
     float4* __restrict__ arena, const KParams* __restrict__ P, const float* __restrict__ actions0,
     const unsigned long long t0, const unsigned long long seed, const long long env_offset, const int n,
     const uint32_t slots,   // bits 0-3 ground-ring read slot, 4-7 ground-ring write slot, 8-11 onboard-ring write slot,
                             // 12-15 ground-ring planes (delay+1, 0 = no ring), 16-19 onboard-ring planes (0 = no ring),
-                            // bit 20: some hlx_info_soa plane is wanted
+                            // bit 20: some hlx_info_soa plane is wanted; 21: all standard planes; 22: observation pipeline;
+                            // 24: the next-episode pool is in use; 25: MODE 2 renews the entries the blocks' masks name (else: every one)
     // ---- ordinary kernarg tail (one scalar load, issued at entry, first needed when results are stored)
     float* __restrict__ obs_out0, float* __restrict__ reward_out0, uint8_t* __restrict__ term_out0,
     uint8_t* __restrict__ trunc_out0,
@@ -202,10 +251,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
     // one scalar compare.  profiles/r02_ab_kernarg_tail_load_pinned.txt: config presets 9.45 -> 8.65 us, base and v2dr unchanged.
     if (RARE(n < 0)) asm volatile("" ::"s"(obs_out0), "s"(reward_out0), "s"(term_out0), "s"(trunc_out0));
     const int lane = threadIdx.x;
-    const int i = blockIdx.x * 64 + lane;
-    const bool live = i < n;
     int g_rslot = (int)(slots & 15u), g_wslot = (int)((slots >> 4) & 15u), o_wslot = (int)((slots >> 8) & 15u);
     const int g_planes = (int)((slots >> 12) & 15u), o_planes = (int)((slots >> 16) & 15u);   // preloaded: no *P needed
+    // ---- next-episode pool (round 3).  The waves that restart an episode used to keep every launch open: spawn draws, float64
+    // spawn trigonometry and a second trip through the observation code for one or two lanes of 64.  All of that is a function
+    // of (seed, environment id, index of the episode) and of constants -- not of the clock -- so it is computed AHEAD, by a
+    // MODE-2 launch for the environments that have used their entry since the last one (one launch every few dozen steps,
+    // several lanes of work per wave instead of one), and a finished lane whose entry is there copies it: state groups,
+    // the ring samples of the first observation and the observation row.  An entry that is not there (the environment
+    // finished twice between two fills, a fused rollout, a pool that is switched off) is computed on the spot by the code
+    // that has always done it -- same keys, same arithmetic, same bits (tests/test_vec_env_gpu.py).
+    // Layout: behind the rings, in the arena allocation, so that every address below derives from preloaded arguments:
+    //   pool [blocks][POOL_GROUPS][64] float4 | tag [blocks * 64] u32 (episode index the entry holds, 0 = none) |
+    //   episode [blocks * 64] u32 (auto-resets so far) | counters int32[4] | used-entry masks [blocks] u64
+    // (Step launches form these addresses inside the rare block that uses them, from an opaque copy of `n`: formed here they
+    // would be loop invariants held in a dozen SGPRs across the whole kernel, and the fused-rollout instantiations have none
+    // to spare -- the spill that followed evicted a hot-constant register, which hotcheck.py refuses.)
+    const PoolPtrs pp2 = MODE == 2 ? pool_ptrs(arena, n, g_planes, o_planes) : PoolPtrs{};
+    // Hot parameter block: two coalesced dword loads per lane now, v_readlane per constant later (hlx_kargs.h).  (The first
+    // vector loads of every instantiation: hotcheck.py identifies the block's registers that way.)
+    uint32_t hotw0 = reinterpret_cast<const uint32_t*>(P)[lane], hotw1 = reinterpret_cast<const uint32_t*>(P)[64 + lane];
+    int i_ = blockIdx.x * 64 + lane;
+    bool live_ = i_ < n;
+    unsigned long long fill_mask = ~0ull;     // MODE 2: the lanes of this block whose entry is to be renewed
+    if (MODE == 2 && (slots & (1u << 25)) != 0u) {
+        // (a scalar load: the mask was written by earlier launches -- one non-returning atomic OR per wave that had a finished
+        // lane; a returning one, for a compacted list, was a memory round trip on the tail of every step launch)
+        fill_mask = *((const __attribute__((address_space(4))) unsigned long long*)pp2.rf_mask + blockIdx.x);
+        if (fill_mask == 0ull) return;
+        if (lane == 0) G(pp2.rf_mask)[blockIdx.x] = 0ull;
+    }
+    const int i = i_;
+    const bool live = live_;
+    uint32_t pool_epn = 0;     // MODE 2: the episode index this lane's entry is computed for
     float* row = tile + lane * HLX_OBS_DIM;
     bool done = false;
     int32_t* done_idx_out = nullptr;   // optional compaction output (read from the hot block inside the live section)
@@ -217,19 +295,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
     asm volatile("" : "+s"(stamp_base));                                     // would charge every segment ~1k cycles
 #endif
     STAMP(0);
-    // Hot parameter block: two coalesced dword loads per lane now, v_readlane per constant later (hlx_kargs.h).
-    uint32_t hotw0 = reinterpret_cast<const uint32_t*>(P)[lane], hotw1 = reinterpret_cast<const uint32_t*>(P)[64 + lane];
     // State loads are issued before anything else, for every lane: the arena is padded to whole 64-env blocks,
     // its pointer arrives preloaded in SGPRs, and nothing here depends on the rest of the kernel arguments.
     // arena layout: [workgroup][group][64 lanes] of 16-byte words -> one contiguous ~11 KiB chunk per wave,
     // group offsets are compile-time constants (no per-group 64-bit address arithmetic in SGPRs)
     float4* A = arena + (size_t)blockIdx.x * (N_GROUPS * 64) + lane;
+    float4* const PA2 = MODE == 2 ? pp2.pool + (size_t)blockIdx.x * (POOL_GROUPS * 64) + lane : nullptr;   // pool fill: this lane's entry
     double2* AD = reinterpret_cast<double2*>(A);
     // this wave's arena block as a buffer (stores only): lane offset in voffset, group offset in soffset
     const __amdgpu_buffer_rsrc_t rsA =
         __builtin_amdgcn_make_buffer_rsrc(arena + (size_t)blockIdx.x * (N_GROUPS * 64), 0, N_GROUPS * 64 * 16, 0x00020000);
     const uint32_t lane16 = (uint32_t)lane * 16u;
-#define STG(G, v) wt16(rsA, lane16, (uint32_t)(G) * 1024u, (v))
+#define STG(Gr, v) do { if (MODE == 2) pool_put(PA2, (Gr), (v)); else wt16(rsA, lane16, (uint32_t)(Gr) * 1024u, (v)); } while (0)
     // ------------------------------------------------------------------ first load batch, issued at entry
     // (the integrator's state groups and the action row); the Philox draws below do not depend on them and run
     // while the loads are in flight.  The Kalman groups and the ring sample follow as a second batch after Philox.
@@ -244,7 +321,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
 #ifndef HLX_MISSILE_LOADS_LATE
 #define HLX_MISSILE_LOADS_LATE 1
 #endif
-    constexpr bool missile_loads_late = HLX_MISSILE_LOADS_LATE && missile_late && LATE && !PERSIST;
+    constexpr bool missile_loads_late = HLX_MISSILE_LOADS_LATE && missile_late && LATE != 0 && !PERSIST;
     float4 g_mpos = make_float4(0.f, 0.f, 0.f, 0.f), g_mvel = g_mpos;
     if (!missile_loads_late) { g_mpos = A[G_MPOS * 64]; g_mvel = A[G_MVEL * 64]; }
     float4 g_thr = make_float4(0.f, 0.f, 0.f, 0.f), g_misc = g_thr;
@@ -260,6 +337,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
     if (need_pow) pow_word = reinterpret_cast<const unsigned long long*>(&HLX_POW_TAB)[lane];
     float4 g_kfp = make_float4(0.f, 0.f, 0.f, 0.f);
     double2 g_kf0 = make_double2(0., 0.), g_kf1 = g_kf0, g_kf2 = g_kf0;
+    // next-episode pool: the environment's episode counter and the tag of its pool entry travel with the Kalman groups (8 bytes
+    // per environment and step), so that a lane that finishes knows at once whether its next episode is waiting -- fetched where
+    // they are needed they were a whole memory round trip on the tail of the launch
+    constexpr bool POOL_PRE = MODE == 0 && !NOISE && !PERSIST;
+    constexpr bool LONE = POOL_PRE && LATE == 2;     // one wave per SIMD: a finished lane's pool entry is requested early, into registers
+    uint32_t pre_ep = 0, pre_tag = 0;
     // (Staging the block in LDS and letting every use be a broadcast ds_read was measured too: 190 fewer
     // instructions, 33 fewer VGPRs, but +0.65 us/step at 65 536 envs -- the lone wave of a SIMD eats each
     // ds_read's latency at the use site, while a v_readlane result is there after its issue cycles.)
@@ -293,13 +376,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         }
         // Kalman groups + delayed ground-ring sample: with the rest at entry when the batch is large (several waves per
         // SIMD: more loads in flight = more HBM bandwidth), as a second batch after Philox when it is small (below)
-        constexpr bool late_loads = LATE;    // instantiation chosen by the host from the batch size
+        constexpr bool late_loads = LATE != 0;    // instantiation chosen by the host from the batch size
         if (!late_loads) {
             if (MODE == 0 && HAS(HLX_F_GROUND)) {   // unconditional when the station exists (the host always allocates >= 1 slot)
                 const float4* R = gring + ((size_t)g_rslot * GROUND_RING_WORDS16) * N + ic;   // slot (t - g_delay) mod cap
                 gr0 = *reinterpret_cast<const double2*>(R); gr1 = R[N]; gr2 = R[2 * N];
             }
             if (!PERSIST) { g_kfp = A[G_KFP * 64]; g_kf0 = AD[G_KF0 * 64]; g_kf1 = AD[G_KF1 * 64]; g_kf2 = AD[G_KF2 * 64]; }
+            if (POOL_PRE) { const PoolPtrs pq = pool_ptrs(arena, n, g_planes, o_planes); pre_tag = G(pq.tag)[ic]; pre_ep = G(pq.ep_cur)[ic]; }
         }
 
         STAMP(1);   // all loads issued
@@ -380,6 +464,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 gr0 = *reinterpret_cast<const double2*>(R); gr1 = R[N]; gr2 = R[2 * N];
             }
             if (!PERSIST) { g_kfp = A[G_KFP * 64 + late]; g_kf0 = AD[G_KF0 * 64 + late]; g_kf1 = AD[G_KF1 * 64 + late]; g_kf2 = AD[G_KF2 * 64 + late]; }
+            if (POOL_PRE) { const PoolPtrs pq = pool_ptrs(arena, n, g_planes, o_planes); pre_tag = G(pq.tag)[ic + late]; pre_ep = G(pq.ep_cur)[ic + late]; }
         }
         PIN4(g_ipos); PIN4(g_ivel); PIN4(g_quat); PIN4(g_w1); PIN2(g_w0);
         if (!missile_late) { PIN4(g_mpos); PIN4(g_mvel); }
@@ -762,7 +847,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             pipe_reward = reward;
         } else {
             // reset-only launch: `done` marks the envs to reset
-            done = HOT(opt.reset_mask) ? (G(HOT(opt.reset_mask))[i] != 0) : true;
+            done = MODE == 2 ? ((fill_mask >> lane) & 1ull) != 0ull      // a pool fill: the environments that used their entry
+                             : (HOT(opt.reset_mask) ? (G(HOT(opt.reset_mask))[i] != 0) : true);
         }
 
         STAMP(7);   // reward
@@ -771,6 +857,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         // these loads placed behind the stores also waits for the stores' acknowledgements -- a store latency stall that a
         // lone wave eats in full (the late loads themselves landed thousands of cycles ago).
         PIN4(g_kfp); PIN2(g_kf0); PIN2(g_kf1); PIN2(g_kf2); PIN2(gr0); PIN4(gr1); PIN4(gr2);
+        if (POOL_PRE) asm volatile("" : "+v"(pre_ep), "+v"(pre_tag));
+        // One observation pass or two?  (see the observation section below)
+        const bool single = MODE == 0 && HOT(opt.terminal_obs) == nullptr && !(slots & (1u << 20));
+        // lone-wave schedule: the prepared episode of a lane that has just finished is requested here -- ahead of the output stores
+        // below, so that waiting for it later does not wait for them -- and is unpacked when the observation pass is over
+        // (`pf` is deliberately left without an initial value: it is written and read under `hit_pf` only, and a zero on the
+        // other path makes the compiler merge the two with copies behind the loads -- i.e. wait for them on the spot)
+        float4 pf[POOL_GROUPS];
+        bool hit_pf = false;
+        if (LONE) {
+            if (RARE(__ballot(done) != 0ull) && (slots & (1u << 24)) != 0u && !single) {
+                hit_pf = done && pre_tag == pre_ep + 1u;
+                if (hit_pf) {
+                    const PoolPtrs pq = pool_ptrs(arena, n, g_planes, o_planes);
+                    const float4* const PA = pq.pool + (size_t)blockIdx.x * (POOL_GROUPS * 64) + lane;
+#pragma unroll
+                    for (int g = 0; g < POOL_GROUPS; ++g) {
+                        const bool used = g <= G_KFP || (g == G_THRUST && (HAS(HLX_F_THRUST_LAG) || HAS(HLX_F_DOMAIN_RAND))) ||
+                                          (g == G_MISC && HAS(HLX_F_DOMAIN_RAND)) ||
+                                          (g >= G_VPOS && g < N_GROUPS && HAS(HLX_F_VOLLEY) && ((g - G_VPOS) % HLX_MAX_VOLLEY) < VK) ||
+                                          (g == PG_ON && HOT(c.o_delay) > 0) ||
+                                          (g >= PG_GR && g < PG_ROW && HAS(HLX_F_GROUND) && HOT(c.g_delay) > 0) || g >= PG_ROW;
+                        if (used) pf[g] = pool_get(PA, g);
+                    }
+                }
+            }
+        }
         // ---------------------------------------------------------------------- early scalar outputs
         // The step's scalar outputs go out now, while ~5k cycles of observation math follow.  (Storing the
         // integrator's state groups here as well was measured: +0.5 us/step at 65 536 envs -- the stores
@@ -874,7 +987,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         // is observed once: the waves that restart an episode -- the ones that keep a launch open -- lose a whole second
         // trip through the observation code.  Outputs are bit-identical either way (bench.py's self-check compares the
         // two forms: the big batch runs single-pass through hlx_rollout, its slabs two-pass through hlx_step).
-        const bool single = MODE == 0 && HOT(opt.terminal_obs) == nullptr && !(slots & (1u << 20));
         // A do-while whose back edge is the rare direction (second trip only when a terminal observation is wanted AND some
         // lane of the wave finished): the common step falls out of the loop without a taken branch.
         int pass = (MODE == 0 ? 0 : 1);
@@ -908,21 +1020,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             float n_on = u_on, n_g = u_g;
             double n_dl = u_dl;
             D3 n_gp = z_gp, n_gv = z_gv;
-            const unsigned long long dmask = (ALLF || pass == 1 || single) ? __ballot(done) : 0ull;
+            unsigned long long dmask = (ALLF || pass == 1 || single) ? __ballot(done) : 0ull;
+            bool hit = false;          // this finished lane's next episode is waiting in the pool: copied, not computed
             if (RARE(dmask != 0ull)) {
+                // Which random numbers start an episode.  An explicit reset (MODE 1) draws from the launch's clock word (+ reset
+                // epoch, hlx.h).  An AUTO-reset draws from (environment id, index of the episode among the environment's
+                // auto-resets): counter words {id, id >> 32, episode, 0xFFFFFF00 | stream} -- the high word is one no clock value
+                // reaches -- so that the episode can be prepared before the step that needs it is known.
+                uint32_t epn = 0;
+                int nn = n;
+                asm volatile("" : "+s"(nn));
+                const PoolPtrs pp = pool_ptrs(arena, nn, g_planes, o_planes);
+                if (MODE != 1 && done) {
+                    epn = (POOL_PRE ? pre_ep : G(pp.ep_cur)[i]) + 1u;
+                    if (POOL_PRE || MODE == 2) {
+                        const uint32_t tag = POOL_PRE ? pre_tag : G(pp.tag)[i];
+                        // (The fused rollout computes its respawns in place: its waves drift apart over the steps of a launch, no
+                        // single step's stragglers hold it open.  So does the single-pass form: there the copy would wait for memory
+                        // exactly where the spawn arithmetic runs today, with nothing saved behind it.)
+                        if (POOL_PRE) hit = LONE ? hit_pf : ((slots & (1u << 24)) != 0u && !single && tag == epn);
+                        if (MODE == 2 && (slots & (1u << 25)) != 0u && tag == epn) done = false;    // renewed since (a fill of every entry)
+                    }
+                    if (MODE == 2) pool_epn = epn;
+                }
+                if (MODE == 2) dmask = __ballot(done);
+                const unsigned long long smask = __ballot(done && !hit);     // the lanes that compute their respawn here
                 float rd[RS_ITEMS][4];
 #pragma unroll
                 for (int j = 0; j < RS_ITEMS; ++j) rd[j][0] = rd[j][1] = rd[j][2] = rd[j][3] = 0.f;
                 asm volatile("" : "+v"(rsalt));
-                const bool wide = (n - (int)blockIdx.x * 64) >= RS_ITEMS;      // lanes 0..10, the ones that serve, are live
-                if (!rnoise_buf) {
+                // lanes 0..10, the ones that serve, are live (a pool fill has every lane at work: each draws for itself)
+                const bool wide = MODE != 2 && (n - (int)blockIdx.x * 64) >= RS_ITEMS;
+                if (!rnoise_buf && smask != 0ull) {
                     if (wide) {
-                        unsigned long long m = dmask;
+                        unsigned long long m = smask;
                         while (m) {
                             const int d = __builtin_ctzll(m);
                             m &= m - 1ull;
                             const unsigned long long gd = (unsigned long long)(env_offset + (long long)blockIdx.x * 64 + d);
-                            const Rng rw{rng.key, (uint32_t)gd, (uint32_t)(gd >> 32), rng.t_lo, rng.t_hi};
+                            const Rng rw{rng.key, (uint32_t)gd, (uint32_t)(gd >> 32), MODE == 1 ? rng.t_lo : (uint32_t)__builtin_amdgcn_readlane(epn, d),
+                                         MODE == 1 ? rng.t_hi : 0xFFFFFFu};
                             const uint4 x = rw.raw((lane < 8 ? 8u : 13u) + (uint32_t)lane);
                             float nz[4], w[4];
                             box_muller(x.x, x.y, nz[0], nz[1]);
@@ -942,14 +1079,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                                 }
                             }
                         }
-                    } else if (done) {
+                    } else if (done && !hit) {
+                        const Rng rk{rng.key, rng.id_lo, rng.id_hi, MODE == 1 ? rng.t_lo : epn, MODE == 1 ? rng.t_hi : 0xFFFFFFu};
                         // (a tail block with fewer than eleven live lanes: the lane draws for itself, one stream per trip of a
                         // ROLLED loop -- this path runs for at most ten environments of a launch and must stay small: the
                         // kernel's code is fetched cold at every launch, and every kilobyte of it is paid by the first wave
                         // of each instruction cache to get there)
 #pragma unroll 1
                         for (int j = 0; j < RS_ITEMS; ++j) {
-                            const uint4 x = rng.raw((j < 8 ? 8u : 13u) + (uint32_t)j + rsalt);
+                            const uint4 x = rk.raw((j < 8 ? 8u : 13u) + (uint32_t)j + rsalt);
                             float w[4], nz[4];
                             box_muller(x.x, x.y, nz[0], nz[1]);
                             box_muller(x.z, x.w, nz[2], nz[3]);
@@ -962,9 +1100,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                         }
                     }
                 }
+                if (MODE == 0 && !PERSIST && (slots & (1u << 24)) != 0u) {
+                    // (the fused rollout records nothing: the host renews every entry behind it)
+                    // these lanes have used their entry: one non-returning atomic OR into the block's mask -- and how many had to
+                    // compute their respawn here (diagnostics: hlx_get_episode_pool_misses)
+                    if (lane == __builtin_ctzll(dmask)) {
+                        (void)__hip_atomic_fetch_or(G(pp.rf_mask) + blockIdx.x, dmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (smask != 0ull) (void)__hip_atomic_fetch_add(G(pp.rf_cnt) + 2, __popcll(smask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
                 if (done) {
                     fresh = true;
-                    if (rnoise_buf) {   // first observation of a new episode: its own draws
+                    if (MODE == 0) G(pp.ep_cur)[i] = epn;
+                    if (hit) {
+                    } else if (rnoise_buf) {   // first observation of a new episode: its own draws
                         const double* B = RN + 10 * N;
                         n_on = (float)B[0]; n_g = (float)B[1 * N]; n_gp = d3(B[2 * N], B[3 * N], B[4 * N]);
                         n_gv = d3(B[5 * N], B[6 * N], B[7 * N]); n_dl = B[8 * N];
@@ -991,6 +1140,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                         if (HOT(opt.info.episode_return)) G(HOT(opt.info.episode_return))[i] = ep_return;
                         if (HOT(opt.info.episode_length)) G(HOT(opt.info.episode_length))[i] = steps;
                     }
+                    if (!hit) {
                     // ---------------- spawn (environment.py:375-567): float64 draws cast to float32
                     const bool rbuf = rnoise_buf;
                     double u[10];
@@ -1104,9 +1254,73 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     p_pp = 1000.f; p_pv = 0.f; p_vp = 0.f; p_vv = 1000.f;
                     prev_distance = reld; last_distance = reld; min_distance = reld; // :579-589
                     worsening = 0; crossed = false;
+                    } else {
+                        // ---------------- the episode was prepared by a pool fill: state groups, ring samples, observation row
+                        // (unpacked exactly as at kernel entry; what the fill stored is what the store section below packs)
+                        const float4* const PA = pp.pool + (size_t)blockIdx.x * (POOL_GROUPS * 64) + lane;
+                        // (lone-wave schedule: the entry was requested before the observation pass and has been parked in the
+                        // accumulation registers since -- the pass needs the ordinary ones; see acc_read)
+                        const auto PL = [&](int g) {
+                            if (!LONE) return pool_get(PA, g);
+                            return make_float4(acc_read(pf[g].x), acc_read(pf[g].y), acc_read(pf[g].z), acc_read(pf[g].w));
+                        };
+                        const auto dbl = [](float lo, float hi) { return __hiloint2double(__float_as_int(hi), __float_as_int(lo)); };
+                        const float4 a = PL(G_IPOS), b = PL(G_IVEL), c = PL(G_QUAT), d = PL(G_MPOS), e4 = PL(G_MVEL), w0 = PL(G_W0), w1 = PL(G_W1);
+                        const float4 k0 = PL(G_KF0), k1 = PL(G_KF1), k2 = PL(G_KF2), kp = PL(G_KFP);
+                        ipos = v3(a.x, a.y, a.z); fuel = a.w;
+                        ivel = v3(b.x, b.y, b.z); prev_distance = b.w;
+                        q = Quat{c.x, c.y, c.z, c.w};
+                        mpos = v3(d.x, d.y, d.z); min_distance = d.w;
+                        mvel = v3(e4.x, e4.y, e4.z); last_distance = e4.w;
+                        wind = d3(dbl(w0.x, w0.y), dbl(w0.z, w0.w), dbl(w1.x, w1.y));
+                        {
+                            const uint32_t pk = __float_as_uint(w1.z);
+                            steps = (int)(pk & 0x1FFFu); worsening = (int)((pk >> 13) & 0xFFFu);
+                            crossed = (pk >> 25) & 1u; kf_init = (pk >> 26) & 1u; kf_x64 = (pk >> 27) & 1u;
+                            on_delay = (int)(pk >> 28);
+                        }
+                        ep_return = w1.w;
+                        kxp = d3(dbl(k0.x, k0.y), dbl(k0.z, k0.w), dbl(k1.x, k1.y));
+                        kxv = d3(dbl(k1.z, k1.w), dbl(k2.x, k2.y), dbl(k2.z, k2.w));
+                        p_pp = kp.x; p_pv = kp.y; p_vp = kp.z; p_vv = kp.w;
+                        if (HAS(HLX_F_THRUST_LAG) || HAS(HLX_F_DOMAIN_RAND)) {
+                            const float4 th = PL(G_THRUST);
+                            thrust_act = v3(th.x, th.y, th.z);
+                            if (HAS(HLX_F_DOMAIN_RAND)) dp.cd_super = th.w;
+                        }
+                        if (HAS(HLX_F_DOMAIN_RAND)) {
+                            const float4 mi = PL(G_MISC);
+                            T0 = dbl(mi.x, mi.y); dp.base_cd = mi.z; dp.peak_m1 = mi.w;
+                        }
+                        if (HAS(HLX_F_VOLLEY)) {
+#pragma unroll
+                            for (int k = 0; k < HLX_MAX_VOLLEY; ++k) {
+                                if (k < VK) {
+                                    const float4 va = PL(G_VPOS + k), vb = PL(G_VVEL + k);
+                                    const uint32_t w = __float_as_uint(vb.w);
+                                    vp[k] = v3(va.x, va.y, va.z); vmin[k] = va.w; vv[k] = v3(vb.x, vb.y, vb.z); vact[k] = (w & 1u) != 0u;
+                                    if (k == 0) { prio = (int)((w >> 8) & 3u); n_int = (int)((w >> 12) & 7u); }
+                                }
+                            }
+                        }
+                        if (HOT(c.o_delay) > 0) on_sample = PL(PG_ON);
+                        if (HAS(HLX_F_GROUND) && HOT(c.g_delay) > 0) {
+                            const float4 s0 = PL(PG_GR), s1 = PL(PG_GR + 1);
+                            g_sp = d3(dbl(s0.x, s0.y), dbl(s0.z, s0.w), dbl(s1.x, s1.y)); g_sq = s1.z; g_sflag = s1.w;
+                            g_s2 = PL(PG_GR + 2);
+                        }
+                        float4 rw[(HLX_OBS_DIM + 3) / 4];
+#pragma unroll
+                        for (int k = 0; k < (HLX_OBS_DIM + 3) / 4; ++k) rw[k] = PL(PG_ROW + k);
+#pragma unroll
+                        for (int k = 0; k < HLX_OBS_DIM; ++k) {
+                            const float4 v = rw[k >> 2];
+                            row[k] = (k & 3) == 0 ? v.x : (k & 3) == 1 ? v.y : (k & 3) == 2 ? v.z : v.w;
+                        }
+                    }
                 }
             }
-            const bool act = ALLF ? done : ((pass == 0) || done);
+            const bool act = (ALLF ? done : ((pass == 0) || done)) && !hit;
             const bool fresh_k = ALLF ? true : fresh;      // (a compile-time `true` in the specialised second trip)
             if (act) {
                 // ======================================================== core.py:511-691 radar detection
@@ -1475,13 +1689,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             }
 #undef PUT4
 #undef PUT2
+            if (MODE == 2) {
+                // pool fill: the samples the first observation would push into the rings, its row, and last the tag that says
+                // which episode of this environment the entry holds (read by step launches that follow on the stream)
+                pool_put(PA2, PG_ON, on_sample);
+                pool_put(PA2, PG_GR, make_double2(g_sp.x, g_sp.y));
+                pool_put(PA2, PG_GR + 1, make_float4(__int_as_float(__double2loint(g_sp.z)), __int_as_float(__double2hiint(g_sp.z)), g_sq, g_sflag));
+                pool_put(PA2, PG_GR + 2, g_s2);
+#pragma unroll
+                for (int k = 0; k < (HLX_OBS_DIM + 3) / 4; ++k)
+                    pool_put(PA2, PG_ROW + k, make_float4(row[4 * k], row[4 * k + 1], 4 * k + 2 < HLX_OBS_DIM ? row[4 * k + 2] : 0.f,
+                                                         4 * k + 3 < HLX_OBS_DIM ? row[4 * k + 3] : 0.f));
+                G(pp2.tag)[i] = pool_epn;
+            }
             const uint32_t blk_bytes = (uint32_t)min(64, n - (int)blockIdx.x * 64) * 16u;   // partial tail block: clip
-            if (HOT(c.o_delay) > 0) {
+            if (MODE != 2 && HOT(c.o_delay) > 0) {
                 const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
                     oring + (size_t)o_wslot * N + (size_t)blockIdx.x * 64, 0, blk_bytes, 0x00020000);
                 wt16(rsO, lane16, 0u, on_sample);
             }
-            if (HAS(HLX_F_GROUND) && HOT(c.g_delay) > 0) {
+            if (MODE != 2 && HAS(HLX_F_GROUND) && HOT(c.g_delay) > 0) {
                 // the slot's three planes are N words apart: one descriptor per plane keeps every offset 32-bit at any N
                 float4* R = gring + ((size_t)g_wslot * GROUND_RING_WORDS16) * N + (size_t)blockIdx.x * 64;
                 wt16(__builtin_amdgcn_make_buffer_rsrc(R, 0, blk_bytes, 0x00020000), lane16, 0u, make_double2(g_sp.x, g_sp.y));

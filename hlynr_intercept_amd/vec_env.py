@@ -463,8 +463,24 @@ class HlynrVecEnv(_SB3VecEnv):
             _lib.check(self._lib.hlx_set_seed(self._h, self._seed))
         return [seed] * self.num_envs
 
+    def set_episode_pool(self, interval: int = -1):
+        """Next-episode pool (hlx.h): `interval` step launches between two fills (-1 = default, 0 = off: every auto-reset is
+        computed inside the step launch that needs it).  Results do not depend on it."""
+        _lib.check(self._lib.hlx_set_episode_pool(self._h, int(interval)))
+
+    @property
+    def episode_pool(self) -> int:
+        return int(self._lib.hlx_get_episode_pool(self._h))
+
+    def episode_pool_misses(self) -> int:
+        """Auto-resets that were computed inside a step launch although the pool was on (diagnostics; synchronises)."""
+        out = C.c_int64(0)
+        _lib.check(self._lib.hlx_get_episode_pool_misses(self._h, C.byref(out)))
+        return int(out.value)
+
     def set_load_schedule(self, mode: int):
-        """-1 auto (by batch size), 0 all loads at kernel entry, 1 Kalman / ring loads behind the Philox block (hlx.h)."""
+        """-1 auto (by batch size), 0 all loads at kernel entry, 1 Kalman / ring loads behind the Philox block, 2 = 1 + the
+        lone-wave schedule for at most one wave per SIMD (hlx.h)."""
         _lib.check(self._lib.hlx_set_load_schedule(self._h, int(mode)))
 
     @property

@@ -160,7 +160,8 @@ typedef struct hlx_env_state {
     float prev_distance, min_distance, last_distance;
     int32_t steps, worsening, crossed, kf_init;
     int32_t kf_x_is64;                  /* the reference's Kalman state array has become float64 (core.py:112) */
-    int32_t pad0;
+    int32_t episode;                    /* auto-resets this environment has gone through since its seed was set: the counter word of
+                                           the NEXT auto-reset's spawn draws is episode + 1 (see hlx_set_episode_pool) */
     double wind[3];                     /* float64 in the reference's simple-wind mode (environment.py:1127-1129) */
     double kf_x[6];
     float kf_P[4];                      /* p_pp, p_pv, p_vp, p_vv : covariance is 3 identical 2x2 blocks */
@@ -285,10 +286,29 @@ int hlx_profile(hlx_env *env, int32_t enable);
  * (synchronises, then clears) */
 int hlx_profile_read(hlx_env *env, double *total_ms, int64_t *launches);
 
-/* Load schedule of the step kernel (two instantiations of the same source, bit-identical results): 1 = the Kalman
+/* Auto-resets and the random streams; the next-episode pool.  The spawn and first-observation draws of an AUTO-reset (an
+ * environment that finishes inside hlx_step / hlx_rollout) are Philox(seed, global env id, k) with k = 1, 2, ... the index of
+ * the episode among that environment's auto-resets since its seed was set (counter words {id, id >> 32, k, 0xFFFFFF00 | stream}:
+ * a high word no clock value reaches) -- not the clock: the episode an environment starts next depends on nothing the steps
+ * before it decide, so the library prepares it ahead of time.  Every `interval` step launches one extra launch computes spawn
+ * state + first observation for the environments that have used their prepared episode since the last one (whole waves of
+ * work), and a finished environment copies its entry inside the step launch instead of computing it there -- which is what
+ * used to keep every step launch open.  An environment that finishes again before its entry has been renewed computes it
+ * on the spot: same draws, same arithmetic, same bits; the pool changes when work is done, never a result.  hlx_reset,
+ * hlx_set_seed (which restarts k), hlx_set_state and a curriculum update that moves the radar beam width or a sensor
+ * reliability renew every entry before the next step launch.  interval: > 0 step launches between fills, 0 = no pool,
+ * -1 = the default (64).  hlx_get_episode_pool returns the interval in force (0 = off).
+ * hlx_get_episode_pool_misses: auto-resets computed inside step launches so far, pool on (synchronises; diagnostics). */
+int hlx_set_episode_pool(hlx_env *env, int32_t interval);
+int32_t hlx_get_episode_pool(const hlx_env *env);
+int hlx_get_episode_pool_misses(hlx_env *env, int64_t *misses);
+
+/* Load schedule of the step kernel (three instantiations of the same source, bit-identical results): 1 = the Kalman
  * groups and the delayed ground-ring sample are loaded as a second batch behind the Philox block (best while a SIMD
- * holds at most two waves), 0 = everything at entry (best once HBM-bound), -1 = choose from the batch size
- * (the default at hlx_create).  hlx_get_load_schedule returns the schedule in force. */
+ * holds at most two waves), 2 = that, and the wave -- alone on its SIMD, with the register file to itself -- requests
+ * the prepared next episode of a lane that finishes as soon as it knows (batches of at most one wave per SIMD: 65 536
+ * environments on an MI355X), 0 = everything at entry (best once HBM-bound), -1 = choose from the batch size (the
+ * default at hlx_create).  hlx_get_load_schedule returns the schedule in force. */
 int hlx_set_load_schedule(hlx_env *env, int32_t mode);
 int32_t hlx_get_load_schedule(const hlx_env *env);
 

@@ -294,7 +294,7 @@ CASES = [
 CASE_IDS = [f"{v}-{s}-{p}-{i}" for i, (s, p, o, v) in enumerate(CASES)]
 
 
-@pytest.mark.parametrize("late", [1, 0], ids=["late-loads", "entry-loads"])
+@pytest.mark.parametrize("late", [2, 1, 0], ids=["lone-wave", "late-loads", "entry-loads"])
 @pytest.mark.parametrize("scenario,physics,over,variant", CASES, ids=CASE_IDS)
 def test_gpu_matches_oracle_free_running(scenario, physics, over, variant, late):
     torch = _torch()

@@ -43,7 +43,15 @@ def test_device_uniforms_are_philox4x32_10_words():
 
             x = words(0)                                   # RS_STEP_U: onboard, ground, datalink, gust uniforms
             assert [sn[11, i], sn[12, i], sn[19, i], sn[6, i]] == [u01(w) for w in x], (for_reset, i)
-            r0, r1, r2 = words(8), words(9), words(10)     # RS_RESET_U0..2: the ten spawn uniforms
+            # RS_RESET_U0..2, the ten spawn uniforms: an explicit reset draws them from the clock word, an auto-reset from the
+            # index of the episode that starts (here the first auto-reset of every environment), under a high word that no
+            # clock value reaches (include/hlx.h, hlx_set_episode_pool)
+            def spawn_words(stream):
+                if for_reset:
+                    return words(stream)
+                return philox4x32((gid & 0xFFFFFFFF, gid >> 32, 1, (0xFFFFFF << 8) | stream), key)
+
+            r0, r1, r2 = spawn_words(8), spawn_words(9), spawn_words(10)
             assert list(rn[0:10, i]) == [u01(w) for w in (*r0, *r1, *r2[:2])], (for_reset, i)
     # ... and a reset with no step in between: epoch 1 at the same clock value
     env.reset()

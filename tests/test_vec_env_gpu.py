@@ -350,27 +350,30 @@ def test_seed_rekeys_the_rng_and_successive_resets_differ():
 @pytest.mark.parametrize("physics,over", [("base", {}), ("v2dr", {}), ("config", {}), ("config", {"volley_mode": True, "volley_size": 3}),
                                           ("v2", {"observation_mode": "los_frame"})])
 def test_both_load_schedules_give_identical_bits(physics, over):
-    """`hlx_set_load_schedule`: the small-batch (LATE) and the large-batch instantiation of the step kernel are the same
-    arithmetic with the Kalman / ring loads issued at different points; outputs and the full state must agree bit for bit,
-    through auto-resets and a partial tail block."""
+    """`hlx_set_load_schedule`: the lone-wave (2), the small-batch (1) and the large-batch (0) instantiation of the step
+    kernel are the same arithmetic with the Kalman / ring loads -- and, in the first, the pool entry of a finished lane --
+    issued at different points; outputs and the full state must agree bit for bit, through auto-resets (episodes shorter
+    and longer than the pool's fill interval) and a partial tail block."""
     import torch
     n, T = 777, 150
     o = dict(over, max_steps=60)
-    a_env, b_env = _env(n, physics, o, seed=21), _env(n, physics, o, seed=21)
-    a_env.set_load_schedule(1); b_env.set_load_schedule(0)
-    assert (a_env.load_schedule, b_env.load_schedule) == (1, 0)
-    assert torch.equal(a_env.reset_torch(), b_env.reset_torch())
+    a_env, b_env, c_env = (_env(n, physics, o, seed=21) for _ in range(3))
+    a_env.set_load_schedule(1); b_env.set_load_schedule(0); c_env.set_load_schedule(2)
+    c_env.set_episode_pool(8)
+    assert (a_env.load_schedule, b_env.load_schedule, c_env.load_schedule) == (1, 0, 2)
+    assert torch.equal(a_env.reset_torch(), b_env.reset_torch()) and torch.equal(a_env.obs, c_env.reset_torch())
     g = torch.Generator(device=a_env.device).manual_seed(2)
     for t in range(T):
         act = torch.rand((n, 6), generator=g, device=a_env.device) * 2 - 1
-        ra, rb = a_env.step_torch(act), b_env.step_torch(act)
-        for x, y in zip(ra[:4], rb[:4]):
-            assert torch.equal(x, y), t
+        ra, rb, rc = a_env.step_torch(act), b_env.step_torch(act), c_env.step_torch(act)
+        for x, y, z in zip(ra[:4], rb[:4], rc[:4]):
+            assert torch.equal(x, y) and torch.equal(x, z), t
         assert torch.equal(ra[4]["terminal_observation"], rb[4]["terminal_observation"])
-    assert bytes(a_env.get_state()) == bytes(b_env.get_state())
+        assert torch.equal(ra[4]["terminal_observation"], rc[4]["terminal_observation"])
+    assert bytes(a_env.get_state()) == bytes(b_env.get_state()) == bytes(c_env.get_state())
     a_env.set_load_schedule(-1)
-    assert a_env.load_schedule == 1                                         # 777 envs: small batch
-    a_env.close(); b_env.close()
+    assert a_env.load_schedule == 2                                         # 777 envs: at most one wave per SIMD
+    a_env.close(); b_env.close(); c_env.close()
 
 
 def _baked_presets():
@@ -606,3 +609,81 @@ def test_reset_options_switch_volley_mode_like_the_reference():
     with pytest.raises(ValueError):
         env.reset(options={"volley_mode": True, "volley_size": 9})
     env.close(); ref.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# round 3: the next-episode pool (hlx.h hlx_set_episode_pool)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("physics,over", [("base", {}), ("v2dr", {}), ("config", {"volley_mode": True, "volley_size": 3}),
+                                          ("config", {"observation_mode": "los_frame"})])
+def test_next_episode_pool_changes_when_work_is_done_never_a_result(physics, over):
+    """Finished environments copy a prepared episode (spawn state, ring samples, first observation) out of the pool, or
+    compute it inside the step launch when the pool is off / the entry has not been renewed yet.  Pool off, a fill
+    after every step, every eight steps, the default interval (longer than the episodes here), the single-pass form and
+    the fused rollout: observations, rewards, flags, terminal observations, info planes and the final state (episode counters
+    included) are the same bits, across many auto-resets, a curriculum update, a masked explicit reset and a state
+    injection on the way."""
+    import torch
+    n, T = 1300, 120
+    over = dict(over, max_steps=19)
+    intervals = [0, 1, 8, -1]
+    envs = [_env(n, physics=physics, over=over, seed=77) for _ in intervals]
+    for e, iv in zip(envs, intervals):
+        e.set_episode_pool(iv)
+        assert e.episode_pool == (64 if iv < 0 else iv)
+        e.reset_torch()
+    g = torch.Generator(device=envs[0].device).manual_seed(12)
+    tape = torch.rand((T, n, 6), generator=g, device=envs[0].device) * 2 - 1
+    mask = (torch.arange(n, device=envs[0].device) % 5 == 0).to(torch.uint8)
+    planes = list(envs[0].info)
+    done_total = 0
+    for t in range(T):
+        if t == 40:
+            for e in envs:
+                e.set_training_step_count(3_000_000)        # moves the radar curriculum where the scenario has one
+        if t == 70:
+            outs = [e.reset_torch(mask).clone() for e in envs]
+            for o in outs[1:]:
+                assert torch.equal(outs[0], o)
+        if t == 95:
+            for e in envs:
+                e.set_state(e.get_state())                   # injection: the pool must not serve what it prepared before
+        ref = None
+        for e in envs:
+            obs, rew, term, trunc, info = e.step_torch(tape[t], want_done_list=True)
+            done = (term | trunc) != 0
+            cur = [obs.clone(), rew.clone(), term.clone(), trunc.clone(), e.terminal_obs[done].clone()] + \
+                  [e.info[k].clone() if k not in ("episode_return", "episode_length") else e.info[k][done].clone() for k in planes]
+            if ref is None:
+                ref = cur
+                done_total += int(done.sum())
+            else:
+                for k, (a, b) in enumerate(zip(ref, cur)):
+                    assert torch.equal(a, b), (t, k, e.episode_pool)
+    assert done_total > 5 * n
+    s0 = bytes(envs[0].get_state())
+    for e in envs[1:]:
+        assert bytes(e.get_state()) == s0
+    st = envs[0].get_state()
+    assert sum(st[i].episode for i in range(n)) > 4 * n
+    # the pool was really used: with a fill behind every step an entry is missing only for environments that the masked reset
+    # or the injection left without one ... and with an interval longer than the episodes it mostly is
+    m_every, m_eight, m_long = (e.episode_pool_misses() for e in envs[1:])
+    assert envs[0].episode_pool_misses() == 0                 # (pool off: nothing is counted)
+    assert m_every < 0.02 * done_total, (m_every, done_total)
+    assert m_every <= m_eight <= m_long and m_long > 0.3 * done_total, (m_every, m_eight, m_long, done_total)
+    # single-pass form and fused rollout against the contract form, pool on
+    a, b, c = (_env(n, physics=physics, over=over, seed=5) for _ in range(3))
+    for e in (a, b, c):
+        e.reset_torch()
+    b.set_rollout_fused(8)
+    outs_a = [x.clone() for x in a.rollout_torch(tape, T)]
+    outs_b = [x.clone() for x in b.rollout_torch(tape, T)]
+    for x, y in zip(outs_a, outs_b):
+        assert torch.equal(x, y)
+    for t in range(T):
+        obs, rew, term, trunc, _ = c.step_torch(tape[t])
+        assert torch.equal(obs, outs_a[0][t]) and torch.equal(rew, outs_a[1][t]) and torch.equal(term, outs_a[2][t]), t
+    assert bytes(a.get_state()) == bytes(b.get_state()) == bytes(c.get_state())
+    for e in envs + [a, b, c]:
+        e.close()
