@@ -371,6 +371,10 @@ def main():
     env = HlynrVecEnv(resolved=rc, num_envs=n, device=local_rank, seed=seed, env_id_offset=offset)
     dev = env.device
     variant = env.kernel_variant      # read now: the handle is gone once the extra points have run
+    pool_info = {"fill_interval_steps": env.episode_pool, "load_schedule": env.load_schedule,
+                 "note": "next-episode pool (include/hlx.h hlx_set_episode_pool): finished environments copy a prepared episode; one fill launch "
+                         "of the step kernel's third mode per fill_interval_steps two-pass step launches -- those launches are INSIDE the "
+                         "event-clocked windows and the wall-clock region, i.e. counted in kernel_us and in value"}
     K, W, D, P = args.steps, args.warmup, max(0, args.desync), max(0, args.preroll)
     R = max(5, -(-400 // max(1, K)))  # event-clocked windows of K launches each
     gen = torch.Generator(device=dev).manual_seed(rank)      # fixed-seed synthetic action tape, U(-1, 1)
@@ -491,6 +495,7 @@ def main():
                  "note": "same K steps through hlx_rollout with hlx_set_rollout_fused: state stays in registers for "
                          "steps_per_launch steps, bit-identical results; not the headline (a policy in the loop needs one launch per step)"}
 
+    pool_info["auto_resets_computed_inside_step_launches"] = env.episode_pool_misses()     # (all forms of this run; the single-pass form and the fused rollout always compute in place)
     # config 3 and a batch whose state (2.6 GB) defeats the 256 MB Infinity Cache -- each in a FRESH process
     # (tools/extra_point.py: at HBM-bound sizes the step's time depends on the process's whole allocation history)
     extra = None
@@ -546,6 +551,7 @@ def main():
             "config": {"workload": f"medium scenario, {args.physics} physics, {n} envs/GPU, fp32 "
                                    f"(BASELINE.json configs[{1 if args.physics == 'base' else 2}])",
                        "envs_per_gpu": n, "kernel_variant": variant, "launches_per_step": 1, "form": forms[0],
+                       "episode_pool": pool_info,
                        "phase": f"steady state: episodes desynchronised by {D} fused-rollout steps, then {P} + {W} untimed steps of the timed form",
                        "sharding": f"{world} x {n} independent envs, no collective in the step"},
             "ranks": {"dist_world_size": dist.get_world_size() if dist is not None else 1, "backend": args.backend if dist is not None else None,

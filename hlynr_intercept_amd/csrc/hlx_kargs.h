@@ -52,7 +52,7 @@ enum : int {
 };
 // bytes behind the rings in the arena allocation, for `blocks` 64-environment blocks: pool | tag u32[] | episode u32[] |
 // int32[4] counters | u64[blocks] masks of the entries used since the last fill
-constexpr int HLX_POOL_INTERVAL_DEFAULT = 64;    // step launches between two pool fills
+constexpr int HLX_POOL_INTERVAL_DEFAULT = 128;    // step launches between two pool fills
 constexpr size_t pool_aux_words16(size_t blocks) { return blocks * 64 * POOL_GROUPS + blocks * 32 + 1 + (blocks + 1) / 2; }
 
 // ---------------------------------------------------------------------------------------------------

@@ -1106,7 +1106,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     // compute their respawn here (diagnostics: hlx_get_episode_pool_misses)
                     if (lane == __builtin_ctzll(dmask)) {
                         (void)__hip_atomic_fetch_or(G(pp.rf_mask) + blockIdx.x, dmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (smask != 0ull) (void)__hip_atomic_fetch_add(G(pp.rf_cnt) + 2, __popcll(smask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (smask != 0ull && !single)      // (the single-pass form computes in place by design: not a miss)
+                            (void)__hip_atomic_fetch_add(G(pp.rf_cnt) + 2, __popcll(smask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
                 if (done) {

@@ -630,7 +630,7 @@ def test_next_episode_pool_changes_when_work_is_done_never_a_result(physics, ove
     envs = [_env(n, physics=physics, over=over, seed=77) for _ in intervals]
     for e, iv in zip(envs, intervals):
         e.set_episode_pool(iv)
-        assert e.episode_pool == (64 if iv < 0 else iv)
+        assert e.episode_pool == (128 if iv < 0 else iv)
         e.reset_torch()
     g = torch.Generator(device=envs[0].device).manual_seed(12)
     tape = torch.rand((T, n, 6), generator=g, device=envs[0].device) * 2 - 1
