@@ -884,6 +884,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 }
             }
         }
+#ifndef HLX_EARLY_STATE_STORES
+#define HLX_EARLY_STATE_STORES 1
+#endif
+#ifndef HLX_EARLY_STATE_POS
+#define HLX_EARLY_STATE_POS 0     // 0: behind the info block (kept); 1: ahead of the scalar outputs (A/B)
+#endif
+        constexpr bool EARLY_ST = HLX_EARLY_STATE_STORES && MODE == 0 && !PERSIST;
+#define HLX_EARLY_BLOCK                                                                    \
+        if (EARLY_ST) {                                                                    \
+            STG(G_IPOS, make_float4(ipos.x, ipos.y, ipos.z, fuel));                        \
+            STG(G_IVEL, make_float4(ivel.x, ivel.y, ivel.z, prev_distance));               \
+            STG(G_QUAT, make_float4(q.w, q.x, q.y, q.z));                                  \
+            STG(G_MPOS, make_float4(mpos.x, mpos.y, mpos.z, min_distance));                \
+            STG(G_MVEL, make_float4(mvel.x, mvel.y, mvel.z, last_distance));               \
+            STG(G_W0, make_double2(wind.x, wind.y));                                       \
+        }
+#if HLX_EARLY_STATE_POS == 1
+        HLX_EARLY_BLOCK
+#endif
         // ---------------------------------------------------------------------- early scalar outputs
         // The step's scalar outputs go out now, while ~5k cycles of observation math follow.  (Storing the
         // integrator's state groups here as well was measured: +0.5 us/step at 65 536 envs -- the stores
@@ -970,6 +989,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         }
 #undef PIN4
 #undef PIN2
+        // The integrator's six state groups are final here for every lane that does not finish: they are stored now, while the
+        // observation section computes and the memory system idles, instead of in the burst at the end of the wave (the store
+        // phase is a fifth of a wave's life: every wave of the launch writes its 24 KB at the same moment); finished lanes,
+        // whose respawn replaces the values, store them again at the end.  Rounds 1 and 2 measured early stores twice and lost
+        // 0.5 us both times (plain stores, one load batch); with write-through stores and the second load batch behind Philox
+        // the same idea gains 0.5 us in the two-pass forms and is neutral in the single-pass one
+        // (profiles/r03_ab_early_state_stores.txt).  Storing MORE early -- the Kalman groups, the packed word and the ring
+        // samples behind the filter -- loses again (9.96 against 9.74), and so does making this block conditional on the form.
+        // -DHLX_EARLY_STATE_STORES=0: everything in the final burst (A/B).
+#if HLX_EARLY_STATE_POS == 0
+        HLX_EARLY_BLOCK
+#endif
         D3 kxp = d3(g_kf0.x, g_kf0.y, g_kf1.x), kxv = d3(g_kf1.y, g_kf2.x, g_kf2.y);
         float p_pp = g_kfp.x, p_pv = g_kfp.y, p_vp = g_kfp.z, p_vv = g_kfp.w;
         // ---------------------------------------------------------------------- observation (+ auto-reset)
@@ -1038,7 +1069,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                         // (The fused rollout computes its respawns in place: its waves drift apart over the steps of a launch, no
                         // single step's stragglers hold it open.  So does the single-pass form: there the copy would wait for memory
                         // exactly where the spawn arithmetic runs today, with nothing saved behind it.)
-                        if (POOL_PRE) hit = LONE ? hit_pf : ((slots & (1u << 24)) != 0u && !single && tag == epn);
+                        // (... and the schedules for more than one wave per SIMD: there the stragglers of one wave are covered by the
+                        // other, and a copy fetched at the end of the pass measured slower than computing -- 16.2 against 15.9 us at
+                        // 131 072 environments.  The host sets bit 24 for the lone-wave schedule only.)
+                        if (POOL_PRE) hit = LONE ? hit_pf : false;
+                        (void)tag;
                         if (MODE == 2 && (slots & (1u << 25)) != 0u && tag == epn) done = false;    // renewed since (a fill of every entry)
                     }
                     if (MODE == 2) pool_epn = epn;
@@ -1428,6 +1463,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     }
                 }
                 const V3 d_gp = to_v3(d_gp64);
+#ifndef HLX_EARLY_MORE
+#define HLX_EARLY_MORE 0      // A/B: 1 = the ground-ring sample is stored behind the ground-radar section; 2 = the Kalman groups and the packed word behind the filter
+#endif
+                if ((HLX_EARLY_MORE & 1) && EARLY_ST && !ALLF && pass == 0 && HAS(HLX_F_GROUND) && HOT(c.g_delay) > 0) {
+                    const uint32_t bb = (uint32_t)min(64, n - (int)blockIdx.x * 64) * 16u;
+                    float4* R = gring + ((size_t)g_wslot * GROUND_RING_WORDS16) * N + (size_t)blockIdx.x * 64;
+                    wt16(__builtin_amdgcn_make_buffer_rsrc(R, 0, bb, 0x00020000), lane16, 0u, make_double2(g_sp.x, g_sp.y));
+                    wt16(__builtin_amdgcn_make_buffer_rsrc(R + N, 0, bb, 0x00020000), lane16, 0u,
+                         make_float4(__int_as_float(__double2loint(g_sp.z)), __int_as_float(__double2hiint(g_sp.z)), g_sq, g_sflag));
+                    wt16(__builtin_amdgcn_make_buffer_rsrc(R + 2 * N, 0, bb, 0x00020000), lane16, 0u, g_s2);
+                }
                 STAMP(9);   // ground radar + ground ring
                 // ---- datalink (core.py:440-474)
                 float datalink = 0.f;
@@ -1529,6 +1575,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                         p_pp = n_pp + HOT(c.q11); p_pv = a_pv + HOT(c.q12); p_vp = n_vp + HOT(c.q12); p_vv = p_vv + HOT(c.q22);
                     }
                     have_track = ALLF ? false : kf_init;
+                }
+                if ((HLX_EARLY_MORE & 2) && EARLY_ST && !ALLF && pass == 0) {
+                    const uint32_t pk = (uint32_t)steps | ((uint32_t)worsening << 13) | ((uint32_t)crossed << 25) |
+                                        ((uint32_t)kf_init << 26) | ((uint32_t)kf_x64 << 27) | ((uint32_t)on_delay << 28);
+                    STG(G_W1, make_float4(__int_as_float(__double2loint(wind.z)), __int_as_float(__double2hiint(wind.z)), __uint_as_float(pk), ep_return));
+                    STG(G_KF0, make_double2(kxp.x, kxp.y));
+                    STG(G_KF1, make_double2(kxp.z, kxv.x));
+                    STG(G_KF2, make_double2(kxv.y, kxv.z));
+                    STG(G_KFP, make_float4(p_pp, p_pv, p_vp, p_vv));
                 }
                 STAMP(11);  // measurement fusion + Kalman filter
                 // ---- observation vector: pure outputs, ordinary fast float32 from here on
@@ -1664,19 +1719,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             // fused rollout: the state stays in the registers it was loaded into; otherwise it goes back to the arena
 #define PUT4(G, reg, ...) do { if (PERSIST) reg = __VA_ARGS__; else STG(G, __VA_ARGS__); } while (0)
 #define PUT2(G, reg, ...) do { if (PERSIST) reg = __VA_ARGS__; else STG(G, __VA_ARGS__); } while (0)
+            if (!EARLY_ST || RARE(done)) {
             PUT4(G_IPOS, g_ipos, make_float4(ipos.x, ipos.y, ipos.z, fuel));
             PUT4(G_IVEL, g_ivel, make_float4(ivel.x, ivel.y, ivel.z, prev_distance));
             PUT4(G_QUAT, g_quat, make_float4(q.w, q.x, q.y, q.z));
             PUT4(G_MPOS, g_mpos, make_float4(mpos.x, mpos.y, mpos.z, min_distance));
             PUT4(G_MVEL, g_mvel, make_float4(mvel.x, mvel.y, mvel.z, last_distance));
             PUT2(G_W0, g_w0, make_double2(wind.x, wind.y));
+            }
             if (HAS(HLX_F_THRUST_LAG) || HAS(HLX_F_DOMAIN_RAND)) PUT4(G_THRUST, g_thr, make_float4(thrust_act.x, thrust_act.y, thrust_act.z, dp.cd_super));
+            if (!((HLX_EARLY_MORE & 2) && EARLY_ST) || RARE(done)) {
             PUT4(G_W1, g_w1, make_float4(__int_as_float(__double2loint(wind.z)), __int_as_float(__double2hiint(wind.z)),
                                          __uint_as_float(packed), ep_return));
             PUT2(G_KF0, g_kf0, make_double2(kxp.x, kxp.y));
             PUT2(G_KF1, g_kf1, make_double2(kxp.z, kxv.x));
             PUT2(G_KF2, g_kf2, make_double2(kxv.y, kxv.z));
             PUT4(G_KFP, g_kfp, make_float4(p_pp, p_pv, p_vp, p_vv));
+            }
             if (HAS(HLX_F_DOMAIN_RAND)) PUT4(G_MISC, g_misc, make_float4(__int_as_float(__double2loint(T0)), __int_as_float(__double2hiint(T0)), dp.base_cd, dp.peak_m1));
             if (HAS(HLX_F_VOLLEY)) {
 #pragma unroll
@@ -1709,7 +1768,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     oring + (size_t)o_wslot * N + (size_t)blockIdx.x * 64, 0, blk_bytes, 0x00020000);
                 wt16(rsO, lane16, 0u, on_sample);
             }
-            if (MODE != 2 && HAS(HLX_F_GROUND) && HOT(c.g_delay) > 0) {
+            if (MODE != 2 && HAS(HLX_F_GROUND) && HOT(c.g_delay) > 0 && (!((HLX_EARLY_MORE & 1) && EARLY_ST) || RARE(done))) {
                 // the slot's three planes are N words apart: one descriptor per plane keeps every offset 32-bit at any N
                 float4* R = gring + ((size_t)g_wslot * GROUND_RING_WORDS16) * N + (size_t)blockIdx.x * 64;
                 wt16(__builtin_amdgcn_make_buffer_rsrc(R, 0, blk_bytes, 0x00020000), lane16, 0u, make_double2(g_sp.x, g_sp.y));
