@@ -859,7 +859,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         PIN4(g_kfp); PIN2(g_kf0); PIN2(g_kf1); PIN2(g_kf2); PIN2(gr0); PIN4(gr1); PIN4(gr2);
         if (POOL_PRE) asm volatile("" : "+v"(pre_ep), "+v"(pre_tag));
         // One observation pass or two?  (see the observation section below)
-        const bool single = MODE == 0 && HOT(opt.terminal_obs) == nullptr && !(slots & (1u << 20));
+        // ... but with the pool at hand (lone-wave schedule) the two-pass flow has no second pass left for a lane whose entry is
+        // there -- it observes its terminal state with everybody else and copies the rest -- and is the faster one even when nobody
+        // wants the terminal observation: 7.87 against 8.29 us (profiles/r03_ab_early_state_stores.txt).  -DHLX_LONE_NEVER_SINGLE=0: A/B.
+#ifndef HLX_LONE_NEVER_SINGLE
+#define HLX_LONE_NEVER_SINGLE 1
+#endif
+        const bool single = MODE == 0 && HOT(opt.terminal_obs) == nullptr && !(slots & (1u << 20)) &&
+                            !(HLX_LONE_NEVER_SINGLE && LONE && (slots & (1u << 24)) != 0u);
         // lone-wave schedule: the prepared episode of a lane that has just finished is requested here -- ahead of the output stores
         // below, so that waiting for it later does not wait for them -- and is unpacked when the observation pass is over
         // (`pf` is deliberately left without an initial value: it is written and read under `hit_pf` only, and a zero on the
