@@ -242,7 +242,11 @@ class HlynrVecEnv(_SB3VecEnv):
         self.reward, self.terminated, self.truncated = v["reward"], v["terminated"], v["truncated"]
         # the kernel counts finished environments straight into the slab (element `vec-step clock & 1`): no copy per step
         self._n_done2 = v["n_done"]
-        self.n_done = self._n_done2[0:1]
+        # per-step host cost matters once the step itself is ~9 us: the two one-element views of the counter pair and the
+        # addresses of the buffers a step always writes are made once, not on every call
+        self._n_done_views = (self._n_done2[0:1], self._n_done2[1:2])
+        self._n_done_ptrs = (self._n_done_views[0].data_ptr(), self._n_done_views[1].data_ptr())
+        self.n_done = self._n_done_views[0]
         _lib.check(self._lib.hlx_set_done_counter(self._h, self._n_done2.data_ptr()))
         self.terminal_obs = torch.zeros((n, _lib.OBS_DIM), dtype=torch.float32, device=dev)
         self.done_idx = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -261,6 +265,10 @@ class HlynrVecEnv(_SB3VecEnv):
                                          self.info["missile_min_distances"].data_ptr() if self.rc.volley_mode else None,
                                          self.info["radar_debug"].data_ptr() if radar_debug else None,
                                          self.info["fuel_used"].data_ptr())
+        self._info_ref = C.byref(self._info_soa)
+        self._ptr_done_idx = self.done_idx.data_ptr()
+        self._step_ptrs = (self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(), self.truncated.data_ptr(),
+                           self.terminal_obs.data_ptr())
         self._actions_dev = torch.zeros((n, _lib.ACT_DIM), dtype=torch.float32, device=dev)
         self._actions_pin = torch.zeros((n, _lib.ACT_DIM), dtype=torch.float32, pin_memory=True)
 
@@ -310,10 +318,9 @@ class HlynrVecEnv(_SB3VecEnv):
         Returns (obs, reward, terminated, truncated, info) - all torch tensors living on the GPU; they are
         overwritten by the next call (clone what must survive)."""
         actions, di, nd = self._step_args(actions, want_done_list)
-        _lib.check(self._lib.hlx_step(self._h, actions.data_ptr(), obs_ptr if obs_ptr is not None else self.obs.data_ptr(),
-                                      self.reward.data_ptr(),
-                                      self.terminated.data_ptr(), self.truncated.data_ptr(),
-                                      self.terminal_obs.data_ptr(), di, nd, C.byref(self._info_soa), self._stream()))
+        p = self._step_ptrs
+        _lib.check(self._lib.hlx_step(self._h, actions.data_ptr(), obs_ptr if obs_ptr is not None else p[0], p[1], p[2], p[3], p[4],
+                                      di, nd, self._info_ref, self._stream()))
         return self.obs, self.reward, self.terminated, self.truncated, self._step_info(want_done_list)
 
     def _step_args(self, actions, want_done_list):
@@ -324,10 +331,11 @@ class HlynrVecEnv(_SB3VecEnv):
         if tuple(actions.shape) != (self.num_envs, _lib.ACT_DIM):
             raise ValueError(f"actions must have shape ({self.num_envs}, {_lib.ACT_DIM}), got {tuple(actions.shape)}")
         # the count of the step about to be issued lands in element (clock & 1) of the slab's counter pair
-        self.n_done = self._n_done2[(int(self._lib.hlx_vec_steps(self._h)) + 1) & 1:][:1]
-        di = self.done_idx.data_ptr() if want_done_list else None
-        nd = self.n_done.data_ptr() if want_done_list else None
-        return actions, di, nd
+        k = (int(self._lib.hlx_vec_steps(self._h)) + 1) & 1
+        self.n_done = self._n_done_views[k]
+        if want_done_list:
+            return actions, self._ptr_done_idx, self._n_done_ptrs[k]
+        return actions, None, None
 
     def _step_info(self, want_done_list):
         info = dict(self.info)
