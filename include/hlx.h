@@ -297,7 +297,9 @@ int hlx_profile_read(hlx_env *env, double *total_ms, int64_t *launches);
  * on the spot: same draws, same arithmetic, same bits; the pool changes when work is done, never a result.  hlx_reset,
  * hlx_set_seed (which restarts k), hlx_set_state and a curriculum update that moves the radar beam width or a sensor
  * reliability renew every entry before the next step launch.  interval: > 0 step launches between fills, 0 = no pool,
- * -1 = the default (128).  hlx_get_episode_pool returns the interval in force (0 = off).
+ * -1 = the default (128).  hlx_get_episode_pool returns the interval in force (0 = off).  Prepared episodes are used by the
+ * lone-wave load schedule only (hlx_set_load_schedule 2: batches of at most one wave per SIMD, where the stragglers of a launch
+ * are exposed); under the other schedules every auto-reset is computed in place, from the same draws, and no fill is launched.
  * hlx_get_episode_pool_misses: auto-resets computed inside step launches so far, pool on (synchronises; diagnostics). */
 int hlx_set_episode_pool(hlx_env *env, int32_t interval);
 int32_t hlx_get_episode_pool(const hlx_env *env);
