@@ -543,6 +543,9 @@ def main():
                 "frac_from_wall_clock": head["algorithmic_bytes_per_launch"] / (wall_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
         for form in forms[1:]:
             roof[form] = measured[form]
+        if "single_pass" in roof and isinstance(roof["single_pass"], dict) and pool_info["fill_interval_steps"] > 0 and pool_info["load_schedule"] == 2:
+            roof["single_pass"]["note"] = ("the form without optional outputs; under the lone-wave schedule with the next-episode pool on it runs the "
+                                           "two-pass flow too (a finished lane copies its prepared episode either way), so the key names the form, not the flow")
         line = {
             "metric": "env-steps/sec whole-node, medium scenario, 64k envs/GPU",
             "value": whole_job_throughput(n, K, world, elapsed), "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
