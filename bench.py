@@ -444,11 +444,15 @@ def main():
         evs[R].record()
         torch.cuda.synchronize(dev)
         us = sorted(1e3 * evs[r].elapsed_time(evs[r + 1]) / K for r in range(R))
-        b = (BYTES_PER_ENV_STEP[args.physics] + FORM_BYTES_DELTA[form]) * n
+        # `frac` / `achieved` are ALWAYS on SURVEY.md 8(d)'s bytes (508 B base, 604 B v2dr per env-step), whatever the form stores,
+        # so that the fraction is comparable across forms and rounds; what this form really moves rides along as *_form_bytes
+        b = BYTES_PER_ENV_STEP[args.physics] * n
+        bf = (BYTES_PER_ENV_STEP[args.physics] + FORM_BYTES_DELTA[form]) * n
         med = us[len(us) // 2] if len(us) % 2 else 0.5 * (us[len(us) // 2 - 1] + us[len(us) // 2])
         return {"kernel_us": med, "window_us": [round(x, 4) for x in us], "windows": R, "launches_per_window": K, "preroll_launches": P,
                 "algorithmic_bytes_per_env_step": b // n, "algorithmic_bytes_per_launch": b,
-                "achieved": b / (med * 1e-6) / 1e9, "frac": b / (med * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                "achieved": b / (med * 1e-6) / 1e9, "frac": b / (med * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "form_bytes_per_env_step": bf // n, "frac_form_bytes": bf / (med * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
     # ---------------------------------------------------------------- the timed region (contract form)
     env.reset_torch()
@@ -536,6 +540,9 @@ def main():
                                                                     f"launch stream) behind {P} launches of the same form, no host sync in between",
                 "window_us": head["window_us"], "algorithmic_bytes_per_env_step": head["algorithmic_bytes_per_env_step"],
                 "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"],
+                "bytes_note": "frac = SURVEY.md 8(d) bytes (508 B base / 604 B v2dr per env-step) x envs / kernel_us / peak, for every form; "
+                              "frac_form_bytes counts what this form stores on top (contract: + 42 B of info planes)",
+                "form_bytes_per_env_step": head["form_bytes_per_env_step"], "frac_form_bytes": head["frac_form_bytes"],
                 "timed_region": {"launches": K, "wall_us_per_step": wall_us,
                                  "note": "the K wall-clock-timed launches between two host synchronisations (what `value` is computed from): "
                                          "includes the cold start behind a synchronisation -- first launch into an empty queue, last kernel "

@@ -93,6 +93,9 @@ def write_vecnormalize_pickle(path: str, state: Dict[str, Any], observation_spac
     obj.__dict__.update(dict(
         venv=None, class_attributes={}, returns=np.zeros(int(num_envs)), num_envs=int(num_envs),
         observation_space=observation_space, action_space=action_space, render_mode=None,
+        # (VecEnv.__init__'s own bookkeeping: a file SB3 2.x wrote carries these too -- tests/golden/sb3/vec_normalize_final.pkl)
+        reset_infos=[{} for _ in range(int(num_envs))], _seeds=[None] * int(num_envs), _options=[{} for _ in range(int(num_envs))],
+        metadata={"render_modes": []},
         norm_obs_keys=None, obs_rms=rms(state["obs_mean"], state["obs_var"], state["obs_count"], (F,)),
         ret_rms=rms(state["ret_mean"], state["ret_var"], state["ret_count"], ()),
         clip_obs=float(state["clip_obs"]), clip_reward=float(state["clip_reward"]), gamma=float(state["gamma"]),

@@ -119,8 +119,10 @@ def test_bench_headline_line_small():
     r = d["roofline"]
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["config"]["form"] == "contract" and r["form"] == "contract"
     assert d["selfcheck"]["ok"] and d["selfcheck"]["batch_equals_slabs_bit_for_bit"] and d["selfcheck"]["obs_env_steps_with_diverged_detection"] == 0
-    assert len(r["window_us"]) == 20 and r["algorithmic_bytes_per_env_step"] == 550
-    assert r["single_pass"]["algorithmic_bytes_per_env_step"] == 500 and r["terminal_obs_only"]["algorithmic_bytes_per_env_step"] == 500
+    # roofline.frac is on SURVEY.md 8(d)'s 508 B for EVERY form (round-3 review); what a form stores on top is reported beside it
+    assert len(r["window_us"]) == 20 and r["algorithmic_bytes_per_env_step"] == 508 and r["form_bytes_per_env_step"] == 550
+    assert r["single_pass"]["algorithmic_bytes_per_env_step"] == 508 and r["terminal_obs_only"]["form_bytes_per_env_step"] == 500
+    assert abs(r["frac"] - 508 * 4096 / (r["kernel_us"] * 1e-6) / 8e12) < 1e-9 and abs(r["frac_form_bytes"] / r["frac"] - 550 / 508) < 1e-9
     for k in (r["kernel_us"], r["single_pass"]["kernel_us"], r["terminal_obs_only"]["kernel_us"], r["frac"], d["value"], d["ms_per_step"]):
         assert _finite(k) and k > 0
     assert d["ranks"]["dist_world_size"] == 1 and len(d["ranks"]["per_rank_ms"]) == 1

@@ -34,6 +34,9 @@ STUB = textwrap.dedent('''
             self.venv, self.num_envs = venv, venv.num_envs
             self.observation_space, self.action_space = venv.observation_space, venv.action_space
             self.class_attributes, self.render_mode = {}, None
+            # VecEnv.__init__ (SB3 2.x): per-env reset bookkeeping + metadata -- present in tests/golden/sb3/vec_normalize_final.pkl
+            self.reset_infos, self._seeds = [{} for _ in range(self.num_envs)], [None for _ in range(self.num_envs)]
+            self._options, self.metadata = [{} for _ in range(self.num_envs)], {"render_modes": []}
             self.norm_obs_keys = norm_obs_keys
             self.obs_rms, self.ret_rms = RunningMeanStd(shape=self.observation_space.shape), RunningMeanStd(shape=())
             self.clip_obs, self.clip_reward = clip_obs, clip_reward
@@ -152,3 +155,75 @@ def test_dict_format_round_trip_and_rejection_of_foreign_files(tmp_path):
         pickle.dump({"something": "else"}, f)
     with pytest.raises(ValueError):
         read_vecnormalize_pickle(q)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# A file Stable-Baselines3 itself wrote (tests/golden/sb3/README.md): pins the on-disk half of SURVEY.md 8 f1.
+GENUINE = os.path.join(ROOT, "tests", "golden", "sb3", "vec_normalize_final.pkl")
+GENUINE_KEYS = {"num_envs", "observation_space", "action_space", "reset_infos", "_seeds", "_options", "render_mode", "metadata",
+                "norm_obs", "norm_obs_keys", "obs_rms", "ret_rms", "clip_obs", "clip_reward", "gamma", "epsilon", "training",
+                "norm_reward", "old_reward", "old_obs"}
+
+
+def _attribute_bag(path):
+    from hlynr_intercept_amd.wrappers import _TolerantUnpickler
+    with open(path, "rb") as f:
+        return _TolerantUnpickler(f).load()
+
+
+def test_genuine_sb3_file_is_read_without_sb3_value_for_value():
+    assert "stable_baselines3" not in sys.modules and "gymnasium" not in sys.modules
+    with pytest.raises((ImportError, AttributeError, ModuleNotFoundError)):
+        with open(GENUINE, "rb") as f:
+            pickle.load(f)                                   # names stable_baselines3 / gymnasium classes
+    d = read_vecnormalize_pickle(GENUINE)
+    assert d["obs_mean"].shape == (17,) and d["obs_mean"].dtype == np.float64 and d["obs_var"].shape == (17,)
+    # spot values read off the file (float64 reprs round-trip exactly)
+    assert d["obs_mean"][0] == 0.5039820088684809 and d["obs_mean"][1] == -1.6107384443599881 and d["obs_mean"][16] == 0.0
+    assert d["obs_var"][0] == 1.3113113488131205 and d["obs_var"][1] == 5.6994204242424145
+    assert d["obs_count"] == 1001480.0001000001 and d["ret_count"] == 1001472.0001000001      # 8 envs: obs counts the reset batch too
+    assert d["ret_mean"] == -14.405738809215823 and d["ret_var"] == 41.546753377302906
+    assert (d["clip_obs"], d["clip_reward"], d["gamma"], d["epsilon"]) == (10.0, 10.0, 0.99, 1e-8)
+    assert (d["norm_obs"], d["norm_reward"], d["training"]) == (True, True, True)
+    # SB3's RunningMeanStd invariants hold in the file: var > 0, constant features sit at the epsilon-count floor
+    assert np.all(d["obs_var"] > 0) and np.isclose(d["obs_var"][16], 1e-4 / d["obs_count"], rtol=1e-6)
+
+
+def test_the_attribute_set_sb3_pickles_is_the_one_this_package_and_the_stand_in_write(tmp_path):
+    bag = _attribute_bag(GENUINE)
+    assert (type(bag).__module__, type(bag).__name__) == ("stable_baselines3.common.vec_env.vec_normalize", "VecNormalize")
+    assert set(bag.__dict__) == GENUINE_KEYS                 # __getstate__ dropped venv / class_attributes / returns
+    assert set(bag.obs_rms.__dict__) == {"mean", "var", "count"} and type(bag.obs_rms).__module__ == "stable_baselines3.common.running_mean_std"
+    assert (type(bag.observation_space).__module__, type(bag.observation_space).__name__) == ("gymnasium.spaces.box", "Box")
+    assert bag.num_envs == 8 and len(bag.reset_infos) == 8 and bag.metadata == {"render_modes": []}
+    # the stand-in the other tests run against pickles exactly this attribute set ...
+    stub = _stub_tree(tmp_path)
+    a, b = str(tmp_path / "stub.pkl"), str(tmp_path / "ours.pkl")
+    _child(f"""
+        import numpy as np
+        from stable_baselines3.common.vec_env import VecNormalize, Box
+        from hlynr_intercept_amd.wrappers import write_vecnormalize_pickle, read_vecnormalize_pickle
+        class Venv: num_envs = 8; observation_space = Box(-1, 1, (17,)); action_space = Box(-1, 1, (6,))
+        VecNormalize(Venv()).save({a!r})
+        # ... and so does this package's writer: genuine file -> our writer -> SB3's own load() -> the same numbers
+        d = read_vecnormalize_pickle({GENUINE!r})
+        assert write_vecnormalize_pickle({b!r}, d, Venv.observation_space, Venv.action_space, 8) == "sb3"
+        v = VecNormalize.load({b!r}, Venv())
+        assert np.array_equal(v.obs_rms.mean, d["obs_mean"]) and np.array_equal(v.obs_rms.var, d["obs_var"])
+        assert v.obs_rms.count == d["obs_count"] and float(v.ret_rms.mean) == d["ret_mean"] and v.ret_rms.count == d["ret_count"]
+    """, stub)
+    for path in (a, b):
+        assert set(_attribute_bag(path).__dict__) == GENUINE_KEYS, path
+    back, d = read_vecnormalize_pickle(b), read_vecnormalize_pickle(GENUINE)
+    for k in d:
+        assert np.array_equal(back[k], d[k]), k
+
+
+def test_genuine_file_round_trips_through_the_dict_format_too(tmp_path):
+    d = read_vecnormalize_pickle(GENUINE)
+    state = dict(d, format="hlynr-vecnormalize-v1", n_stack=1)
+    p = str(tmp_path / "dict.pkl")
+    assert write_vecnormalize_pickle(p, state, None, None, 8) == "dict"
+    back = read_vecnormalize_pickle(p)
+    for k in d:
+        assert np.array_equal(back[k], d[k]), k

@@ -41,10 +41,11 @@ def main():
             env.rollout_torch(tape[lo:hi], 8)
         torch.cuda.synchronize(env.device)
         dt = time.perf_counter() - t0
-        b = BYTES_PER_ENV_STEP[phys] + FORM_BYTES_DELTA[form]
+        b, bf = BYTES_PER_ENV_STEP[phys], BYTES_PER_ENV_STEP[phys] + FORM_BYTES_DELTA[form]     # SURVEY.md 8(d) bytes; what this form stores
         out.append({"workload": f"medium scenario, {phys} physics, {n} envs/GPU", "form": form, "value": n * k / dt, "unit": "env-steps/s",
-                    "us_per_step": 1e6 * dt / k, "algorithmic_bytes_per_env_step": b, "desync_steps": d, "steps": k, "process": "fresh",
-                    "roofline_frac": n * k * b / dt / 1e9 / HBM_PEAK_GBS})
+                    "us_per_step": 1e6 * dt / k, "algorithmic_bytes_per_env_step": b, "form_bytes_per_env_step": bf, "desync_steps": d,
+                    "steps": k, "process": "fresh", "roofline_frac": n * k * b / dt / 1e9 / HBM_PEAK_GBS,
+                    "roofline_frac_form_bytes": n * k * bf / dt / 1e9 / HBM_PEAK_GBS})
     env.close()
     print(json.dumps(out), flush=True)
 
