@@ -13,6 +13,7 @@ from . import build as _build
 f32, i32, u32, i64, u64, f64, u8p = C.c_float, C.c_int32, C.c_uint32, C.c_int64, C.c_uint64, C.c_double, C.c_void_p
 
 OBS_DIM, ACT_DIM, STEP_SLOTS, RESET_SLOTS, RING_CAP, MAX_STEPS, MAX_VOLLEY = 26, 6, 32, 48, 11, 8191, 4
+ABI_VERSION = 4      # include/hlx.h HLX_ABI_VERSION: the revision these ctypes mirrors were written for
 
 # hlx_flags
 F_ATMOSPHERE, F_MACH_DRAG, F_ENH_WIND, F_THRUST_LAG, F_DOMAIN_RAND, F_VALIDATION, F_EVASION, F_PRECISION = (
@@ -50,7 +51,8 @@ class HlxInfoSoa(C.Structure):
     _fields_ = [("distance", C.c_void_p), ("min_distance", C.c_void_p), ("fuel", C.c_void_p), ("flags", C.c_void_p),
                 ("episode_return", C.c_void_p), ("episode_length", C.c_void_p), ("missiles", C.c_void_p),
                 ("interceptor_pos", C.c_void_p), ("missile_pos", C.c_void_p), ("steps", C.c_void_p),
-                ("missile_min_distances", C.c_void_p), ("radar_debug", C.c_void_p), ("fuel_used", C.c_void_p)]
+                ("missile_min_distances", C.c_void_p), ("radar_debug", C.c_void_p), ("fuel_used", C.c_void_p),
+                ("packed", C.c_void_p)]
 
 
 class HlxEnvState(C.Structure):
@@ -65,6 +67,7 @@ class HlxEnvState(C.Structure):
         ("T0", f64), ("base_cd", f32), ("transonic_peak_m1", f32), ("cd_super", f32), ("ep_return", f32),
         ("v_pos", (f32 * 3) * MAX_VOLLEY), ("v_vel", (f32 * 3) * MAX_VOLLEY), ("v_min", f32 * MAX_VOLLEY),
         ("v_active", i32 * MAX_VOLLEY), ("prio", i32), ("n_intercepted", i32),
+        ("fuel_used", f32), ("pad2", i32),
     ]
 
 
@@ -107,6 +110,7 @@ SYMBOLS = {
     "hlx_set_episode_pool": (C.c_int, [_P, i32]),
     "hlx_get_episode_pool": (i32, [_P]),
     "hlx_get_episode_pool_misses": (C.c_int, [_P, C.POINTER(i64)]),
+    "hlx_get_episode_pool_stats": (C.c_int, [_P, C.POINTER(i64 * 4)]),
     "hlx_set_load_schedule": (C.c_int, [_P, i32]),
     "hlx_get_load_schedule": (i32, [_P]),
     "hlx_profile": (C.c_int, [_P, i32]),
@@ -117,6 +121,8 @@ SYMBOLS = {
     "hlx_kernel_baked": (C.c_char_p, [_P]),
     "hlx_sizeof_config": (i32, []),
     "hlx_sizeof_env_state": (i32, []),
+    "hlx_sizeof_info_soa": (i32, []),
+    "hlx_abi_version": (i32, []),
     "hlx_last_error": (C.c_char_p, []),
     "hlx_version": (C.c_char_p, []),
     # include/hlx_obs.h
@@ -200,13 +206,25 @@ def _load(build_if_missing: bool):
         lib = C.CDLL(path)
     except OSError as exc:
         raise RuntimeError(f"cannot load {path} (is the ROCm runtime, libamdhip64, present?): {exc}") from exc
+    # ABI guard first -- also on the cannot-rebuild path above, and for an HLX_LIBRARY override: a library from another
+    # revision of include/hlx.h (a struct that grew, an entry point that changed meaning) is refused, not half-used
+    try:
+        abi = lib.hlx_abi_version
+    except AttributeError as exc:
+        raise RuntimeError(f"{path} predates hlx_abi_version(): it was built from another revision of include/hlx.h; rebuild it "
+                           "(python -m hlynr_intercept_amd.build)") from exc
+    abi.restype, abi.argtypes = i32, []
+    if abi() != ABI_VERSION:
+        raise RuntimeError(f"{path} implements ABI revision {abi()} of include/hlx.h, this binding revision {ABI_VERSION}: rebuild it "
+                           "(python -m hlynr_intercept_amd.build)")
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)   # AttributeError = symbol missing = broken build
         fn.restype, fn.argtypes = res, args
-    if lib.hlx_sizeof_config() != C.sizeof(HlxConfig):
-        raise RuntimeError(f"hlx_config layout mismatch: C {lib.hlx_sizeof_config()} vs ctypes {C.sizeof(HlxConfig)}")
-    if lib.hlx_sizeof_env_state() != C.sizeof(HlxEnvState):
-        raise RuntimeError("hlx_env_state layout mismatch")
+    for what, c_size, py_size in (("hlx_config", lib.hlx_sizeof_config(), C.sizeof(HlxConfig)),
+                                  ("hlx_env_state", lib.hlx_sizeof_env_state(), C.sizeof(HlxEnvState)),
+                                  ("hlx_info_soa", lib.hlx_sizeof_info_soa(), C.sizeof(HlxInfoSoa))):
+        if c_size != py_size:
+            raise RuntimeError(f"{what} layout mismatch: C {c_size} vs ctypes {py_size} bytes")
     _lib = lib
     return lib
 

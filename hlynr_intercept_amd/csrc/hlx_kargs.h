@@ -34,11 +34,22 @@ enum : int {
     G_KFP,       // float4: covariance block p_pp, p_pv, p_vp, p_vv
     G_THRUST,    // float4: actual thrust xyz (thrust lag), F(base_cd * supersonic_multiplier)   [thrust lag / domain randomisation]
     G_MISC,      // {double T0, float F(base_cd), float F(peak multiplier - 1)}   [domain randomisation only]
+#ifndef HLX_AB_AUX_ALIAS
+    G_AUX,       // a plane of DWORDS, not of 16-byte words: dword `lane` = float total_fuel_used (environment.py:886) -- 4 bytes per
+                 // environment read and written per step (256 B per wave); the rest of the 1 KiB slot is unused address space
+#endif
     G_VPOS,      // float4 x HLX_MAX_VOLLEY: volley missile k position xyz, its minimum distance        [volley only]
     G_VVEL = G_VPOS + HLX_MAX_VOLLEY,   // float4 x HLX_MAX_VOLLEY: velocity xyz, bits: 0 active | 8-9 priority index |
                                         // 12-14 missiles intercepted (the last two in missile 0's word only)
+#ifdef HLX_AB_PAD_GROUPS       // timing experiments only: extra (unused) groups, i.e. another block stride
+    N_GROUPS = G_VVEL + HLX_MAX_VOLLEY + HLX_AB_PAD_GROUPS
+#else
     N_GROUPS = G_VVEL + HLX_MAX_VOLLEY
+#endif
 };
+#ifdef HLX_AB_AUX_ALIAS            // timing experiments only: the dword plane shares the last volley group (block stride as in round 3)
+constexpr int G_AUX = G_VVEL + HLX_MAX_VOLLEY - 1;
+#endif
 // ground ring slot: double2 {rel_pos x, y}, {double rel_pos z, float quality, float sample-was-a-detection}, float4 {rel_vel xyz, pad}
 constexpr int GROUND_RING_WORDS16 = 3;
 // Next-episode pool entry (hlx_kernels.hip, "next-episode pool"): the state groups as a respawned lane would store them, the
@@ -53,6 +64,7 @@ enum : int {
 // bytes behind the rings in the arena allocation, for `blocks` 64-environment blocks: pool | tag u32[] | episode u32[] |
 // int32[4] counters | u64[blocks] masks of the entries used since the last fill
 constexpr int HLX_POOL_INTERVAL_DEFAULT = 128;    // step launches between two pool fills
+constexpr int HLX_POOL_QUIET_STEPS = 16;          // step launches a moving sensor reliability must have stood still before the pool is filled again
 constexpr size_t pool_aux_words16(size_t blocks) { return blocks * 64 * POOL_GROUPS + blocks * 32 + 1 + (blocks + 1) / 2; }
 
 // ---------------------------------------------------------------------------------------------------

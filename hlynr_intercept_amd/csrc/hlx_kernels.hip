@@ -55,9 +55,6 @@ namespace {
 #define HLX_INFO_RARE 0
 #endif
 #define INFO_WANTED(x) (HLX_INFO_RARE ? RARE(x) : (x))
-#ifndef HLX_INFO_FAST
-#define HLX_INFO_FAST 1
-#endif
 // Pointers that reach the kernel through the hot block (optional outputs) or through *P are GENERIC to the compiler, and a
 // generic access is a FLAT instruction: it counts in vmcnt AND lgkmcnt, may complete out of order with the global ones, and while
 // one may be pending every later `s_waitcnt vmcnt(n)` the compiler emits becomes vmcnt(0) -- on every path, taken or not.  (Found
@@ -106,6 +103,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 DEV void wt16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, float4 v) {
     u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
     __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, HLX_ST_AUX);
+}
+#ifndef HLX_INFO_AUX
+#define HLX_INFO_AUX HLX_ST_AUX   // cache bits of the packed info stores (A/B: 0 = plain)
+#endif
+DEV void wt16i(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, float4 v) {      // hlx_info_soa.packed words
+    u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, HLX_INFO_AUX);
 }
 // (pool entries: plain per-lane stores -- a fill touches a few thousand environments)
 struct PoolPtrs {
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
     const unsigned long long t0, const unsigned long long seed, const long long env_offset, const int n,
     const uint32_t slots,   // bits 0-3 ground-ring read slot, 4-7 ground-ring write slot, 8-11 onboard-ring write slot,
                             // 12-15 ground-ring planes (delay+1, 0 = no ring), 16-19 onboard-ring planes (0 = no ring),
-                            // bit 20: some hlx_info_soa plane is wanted; 21: all standard planes; 22: observation pipeline;
+                            // bit 20: some hlx_info_soa plane is wanted; 22: observation pipeline; 23: hlx_info_soa.packed is given;
                             // 24: the next-episode pool is in use; 25: MODE 2 renews the entries the blocks' masks name (else: every one)
     // ---- ordinary kernarg tail (one scalar load, issued at entry, first needed when results are stored)
     float* __restrict__ obs_out0, float* __restrict__ reward_out0, uint8_t* __restrict__ term_out0,
@@ -308,6 +312,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         __builtin_amdgcn_make_buffer_rsrc(arena + (size_t)blockIdx.x * (N_GROUPS * 64), 0, N_GROUPS * 64 * 16, 0x00020000);
     const uint32_t lane16 = (uint32_t)lane * 16u;
 #define STG(Gr, v) do { if (MODE == 2) pool_put(PA2, (Gr), (v)); else wt16(rsA, lane16, (uint32_t)(Gr) * 1024u, (v)); } while (0)
+    // ... and the dword plane G_AUX (a pool entry holds none: an episode starts with total_fuel_used = 0)
+#ifndef HLX_AB_NO_FU
+#define HLX_AB_NO_FU 0      // timing experiments only: 1 = total_fuel_used neither loaded nor stored
+#endif
+#ifndef HLX_AB_AUX_LATE
+#define HLX_AB_AUX_LATE 0   // A/B: 1 = the total_fuel_used dword is stored in the final burst, not with the early state groups
+#endif
+#ifndef HLX_INFO_W2
+#define HLX_INFO_W2 0       // where hlx_info_soa.packed word 2 leaves: 0 = behind observation pass 0, complete; 1 = with words 0 and 1, and
+#endif                      // its flag dword once more at the end of the kernel, with the detection bits (A/B)
+#ifndef HLX_DONE_LATE
+#define HLX_DONE_LATE 0     // 1 = the done list is compacted behind the observation tile's stores instead of ahead of them (A/B)
+#endif
+#define STAUX(v) do { if (MODE != 2 && !HLX_AB_NO_FU) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsA, (uint32_t)lane * 4u, (uint32_t)G_AUX * 1024u, HLX_ST_AUX); } while (0)
     // ------------------------------------------------------------------ first load batch, issued at entry
     // (the integrator's state groups and the action row); the Philox draws below do not depend on them and run
     // while the loads are in flight.  The Kalman groups and the ring sample follow as a second batch after Philox.
@@ -328,6 +346,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
     float4 g_thr = make_float4(0.f, 0.f, 0.f, 0.f), g_misc = g_thr;
     if (HAS(HLX_F_THRUST_LAG) || HAS(HLX_F_DOMAIN_RAND)) g_thr = A[G_THRUST * 64];   // .w: a domain-randomised constant
     if (HAS(HLX_F_DOMAIN_RAND)) g_misc = A[G_MISC * 64];
+    // `total_fuel_used` (environment.py:204, 566, 886; info['fuel_used']): environment state since round 4 -- one dword per lane of
+    // the G_AUX plane (256 B per wave), in the arena like everything else, so that it travels through hlx_get_state / hlx_set_state
+    // and advances in every form of the step.  (Round 3 kept it in the CALLER's info plane: a checkpoint lost it.)
+    float* const AUX = reinterpret_cast<float*>(arena + (size_t)blockIdx.x * (N_GROUPS * 64) + G_AUX * 64) + lane;
+    float g_fu = 0.f;
+    if (MODE == 0 && !HLX_AB_NO_FU) g_fu = *G(AUX);
     // Everything down to the construction of `hot` runs with ALL lanes enabled: the constants are fetched with
     // cross-lane reads (v_readlane), so the lanes that hold them must have executed their loads even in a partial
     // tail block; padding lanes use the last live environment's addresses and their results are discarded.
@@ -425,8 +449,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 float ua = u01(x.x), ub = u01(x.y), uc = u01(x.z), ud = u01(x.w);
                 // keep the block here (the optimiser would otherwise sink each chain to its first use, behind
                 // the loads it is meant to overlap)
+#ifndef HLX_PHILOX_PIN
+#define HLX_PHILOX_PIN 3    // which draws are pinned in front of the first use of loaded state: 3 = all sixteen (rounds 1-3); 2 = not the
+#endif                      // ground-measurement normals of call N2 (first needed in the observation section); 1 = nor the four uniforms (A/B)
                 asm volatile("" : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "+v"(n4), "+v"(n5), "+v"(n6), "+v"(n7));
-                asm volatile("" : "+v"(n8), "+v"(n9), "+v"(n10), "+v"(n11), "+v"(ua), "+v"(ub), "+v"(uc), "+v"(ud));
+                if (HLX_PHILOX_PIN >= 3) asm volatile("" : "+v"(n8), "+v"(n9), "+v"(n10), "+v"(n11));
+                if (HLX_PHILOX_PIN >= 2) asm volatile("" : "+v"(ua), "+v"(ub), "+v"(uc), "+v"(ud));
                 z_ev = d3((double)n0, (double)n1, (double)n2);
                 z_wind = d3((double)n3, (double)n4, (double)n5);
                 z_gp = d3((double)n6, (double)n7, (double)n8);
@@ -471,6 +499,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         if (!missile_late) { PIN4(g_mpos); PIN4(g_mvel); }
         if (HAS(HLX_F_THRUST_LAG) || HAS(HLX_F_DOMAIN_RAND)) PIN4(g_thr);
         if (HAS(HLX_F_DOMAIN_RAND)) PIN4(g_misc);
+        if (MODE == 0) asm volatile("" : "+v"(g_fu));
         PIN2(a01); PIN2(a23); PIN2(a45);
         // (the Kalman / ring registers are released further down, right before the observation section)
         // the output pointers of the kernarg tail have landed by now
@@ -481,10 +510,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             WAVE_LDS_SYNC();   // one wave per workgroup: orders the LDS writes before the per-lane lookups below
         }
         done_idx_out = HOT(opt.done_idx);
-        // info['fuel_used'] (environment.py:886) accumulates in the CALLER's plane (hlx.h): last step's value is fetched here, as
-        // soon as the hot words can be read, and is first needed in the info block a whole physics section later
-        float fuel_used_prev = 0.f;
-        if (MODE == 0 && INFO_WANTED(slots & (1u << 20)) && HOT(opt.info.fuel_used)) fuel_used_prev = G(HOT(opt.info.fuel_used))[ic];
         // (the same for the observation pipeline's discounted returns, when one rides on this launch)
         if (MODE == 0 && !PERSIST && RARE(slots & (1u << 22)) && HOT(opt.pipe_returns)) pipe_ret_prev = G(HOT(opt.pipe_returns))[ic];
         if (live) {   // ============================== per-environment work, live lanes only ==============================
@@ -495,6 +520,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         if (!missile_late) { mpos = v3(g_mpos.x, g_mpos.y, g_mpos.z); mvel = v3(g_mvel.x, g_mvel.y, g_mvel.z); }
         D3 wind = d3(g_w0.x, g_w0.y, __hiloint2double(__float_as_int(g_w1.y), __float_as_int(g_w1.x)));
         float fuel = g_ipos.w, prev_distance = g_ivel.w, min_distance = 0.f, last_distance = 0.f;
+        float fuel_used = g_fu;                                                      // environment.py:204 total_fuel_used
         if (!missile_late) { min_distance = g_mpos.w; last_distance = g_mvel.w; }
         uint32_t packed = __float_as_uint(g_w1.z);
         float ep_return = g_w1.w;
@@ -530,7 +556,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             }
         }
 
-        float fuel_step = 0.f;   // this step's fuel consumption (environment.py:884)
         float reward = 0.f, distance = 0.f, range_c = 0.f;   // range_c: ||missile - interceptor|| of the state the observation will see
         bool terminated = false, truncated = false, intercepted = false, hit_target = false, fuze = false,
              clamped = false;
@@ -576,7 +601,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             }
             float fc = (divc(snorm3(thr), 1.0 / 500.0) * 0.1f) * HOT(c.dt);              // :883-884
             fuel = fuel - fc;
-            fuel_step = fc;
+            fuel_used = fuel_used + fc;                                              // :886 (float32 running sum, 0 at reset :566)
             if (RARE(fuel <= 0.f)) { fuel = 0.f; thr = v3(0.f, 0.f, 0.f); thrust_act = thr; } // :888-892
             const V3 tacc = divc(thr, 1.0 / 500.0);                                 // :896
             float rho = 1.225f, sos = 343.f;
@@ -908,6 +933,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             STG(G_MPOS, make_float4(mpos.x, mpos.y, mpos.z, min_distance));                \
             STG(G_MVEL, make_float4(mvel.x, mvel.y, mvel.z, last_distance));               \
             STG(G_W0, make_double2(wind.x, wind.y));                                       \
+            if (!HLX_AB_AUX_LATE) STAUX(fuel_used);                                        \
         }
 #if HLX_EARLY_STATE_POS == 1
         HLX_EARLY_BLOCK
@@ -916,84 +942,58 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         // The step's scalar outputs go out now, while ~5k cycles of observation math follow.  (Storing the
         // integrator's state groups here as well was measured: +0.5 us/step at 65 536 envs -- the stores
         // contend with the tail of the entry loads -- so the state groups stay in the final store section.)
+        uint32_t info_word = 0;     // hlx_info_soa: bits 0-4 of `flags`, `missiles` << 8, terminated << 16, truncated << 17
+        __amdgpu_buffer_rsrc_t rsI = rsA;   // hlx_info_soa.packed as a buffer (set where the first two words are stored)
         if (MODE == 0) {
             reward_out[i] = reward;
             term_out[i] = terminated ? 1 : 0;
             trunc_out[i] = truncated ? 1 : 0;
             if (INFO_WANTED(slots & (1u << 20))) {   // some hlx_info_soa plane is wanted (one SGPR test instead of nine pointer fetches)
-#if HLX_INFO_FAST
-            if (slots & (1u << 21)) {
-                // The contract form (every plane a VecEnv facade passes, hlx_host.inc ring_slots): no null tests, and buffer stores off
-                // scalar bases -- the plane's address stays in SGPRs and all dword planes share ONE 32-bit lane offset, where the
-                // generic form below spends ~12 instructions per plane on a null test, two v_mov and a 64-bit add (round 3: the block
-                // was 110 instructions of every wave of the headline launch).
-                const uint32_t o4 = (uint32_t)i * 4u, plane = (uint32_t)n * 4u;
-#define INFO_RS(p) __builtin_amdgcn_make_buffer_rsrc((void*)(p), 0, 0x7FFFFFFF, 0x00020000)
-#define INFO_ST32(p, soff, val) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), INFO_RS(p), o4, (soff), 0)
-                INFO_ST32(HOT(opt.info.distance), 0u, distance);
-                INFO_ST32(HOT(opt.info.min_distance), 0u, min_distance);
-                INFO_ST32(HOT(opt.info.fuel), 0u, fuel);
-                INFO_ST32(HOT(opt.info.fuel_used), 0u, (steps == 1) ? fuel_step : fuel_used_prev + fuel_step);   // :886
+                // info['intercepted' | 'missile_hit_target' | 'proximity_fuze_triggered' | 'clamped' | 'crossed_threshold'] (:829-857) and
+                // info['missiles_*'] (:846-847) as they stand at the END OF THE STEP, before an auto-reset clears them (until round 3
+                // `crossed_threshold` of a finished environment was read after its respawn, i.e. always False); the detection bits
+                // join when observation pass 0 has decided them
                 {
-                    const __amdgpu_buffer_rsrc_t ri = INFO_RS(HOT(opt.info.interceptor_pos)), rm = INFO_RS(HOT(opt.info.missile_pos));   // :836-838
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ipos.x), ri, o4, 0u, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ipos.y), ri, o4, plane, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ipos.z), ri, o4, 2u * plane, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mpos.x), rm, o4, 0u, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mpos.y), rm, o4, plane, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mpos.z), rm, o4, 2u * plane, 0);
-                }
-                __builtin_amdgcn_raw_buffer_store_b32((uint32_t)steps, INFO_RS(HOT(opt.info.steps)), o4, 0u, 0);
-                {                                                                     // :846-847
                     int remaining = intercepted ? 0 : 1, got = intercepted ? 1 : 0;
                     if (HAS(HLX_F_VOLLEY)) {
                         remaining = 0; got = n_int;
 #pragma unroll
                         for (int k = 0; k < HLX_MAX_VOLLEY; ++k) remaining += (k < VK && vact[k]) ? 1 : 0;
                     }
-                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(got | (remaining << 4)), INFO_RS(HOT(opt.info.missiles)), (uint32_t)i, 0u, 0);
+                    info_word = (intercepted ? 1u : 0u) | (hit_target ? 2u : 0u) | (fuze ? 4u : 0u) | (clamped ? 8u : 0u) | (crossed ? 16u : 0u) |
+                                ((uint32_t)(got | (remaining << 4)) << 8) | (terminated ? 1u << 16 : 0u) | (truncated ? 1u << 17 : 0u);
                 }
-                if (HAS(HLX_F_VOLLEY) && HOT(opt.info.missile_min_distances)) {       // :848
-                    const __amdgpu_buffer_rsrc_t rv = INFO_RS(HOT(opt.info.missile_min_distances));
-#pragma unroll
-                    for (int k = 0; k < HLX_MAX_VOLLEY; ++k) if (k < VK) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vmin[k]), rv, o4, (uint32_t)k * plane, 0);
+                if (slots & (1u << 23)) {
+                    // hlx_info_soa.packed, the form a VecEnv facade passes (hlx.h): the nine standard keys as three 16-byte words per
+                    // environment, stored like state groups -- one coalesced 16-byte-per-lane instruction each -- where rounds 1-3 issued
+                    // eleven 4-byte and four 1-byte stores (1.15 us of the 8.9 us launch for 7.6 % of its bytes).  Words 0 and 1 are
+                    // final here; word 2 (missile position + the flag word) leaves behind observation pass 0.
+                    rsI = __builtin_amdgcn_make_buffer_rsrc((void*)HOT(opt.info.packed), 0, 0x7FFFFFFF, 0x00020000);
+                    wt16i(rsI, (uint32_t)i * 16u, 0u, make_float4(distance, min_distance, fuel, fuel_used));
+                    wt16i(rsI, (uint32_t)i * 16u, (uint32_t)n * 16u, make_float4(ipos.x, ipos.y, ipos.z, __int_as_float(steps)));   // :836-838
+                    if (HLX_INFO_W2 == 1) wt16i(rsI, (uint32_t)i * 16u, (uint32_t)n * 32u, make_float4(mpos.x, mpos.y, mpos.z, __uint_as_float(info_word)));
                 }
-#undef INFO_ST32
-#undef INFO_RS
-            }
-            if (RARE(!(slots & (1u << 21)))) {     // (an `if` of its own behind RARE(), not an `else`: the block then sits out of line)
-#endif
-            if (HOT(opt.info.distance)) G(HOT(opt.info.distance))[i] = distance;
-            if (HOT(opt.info.min_distance)) G(HOT(opt.info.min_distance))[i] = min_distance;
-            if (HOT(opt.info.fuel)) G(HOT(opt.info.fuel))[i] = fuel;
-            if (HOT(opt.info.fuel_used))    // :886 `self.total_fuel_used += fuel_consumed` (float32; 0 at reset, :566)
-                G(HOT(opt.info.fuel_used))[i] = (steps == 1) ? fuel_step : fuel_used_prev + fuel_step;
-            if (HOT(opt.info.interceptor_pos)) {                                  // :836-838 (post-step, pre-respawn values)
-                auto ip = G(HOT(opt.info.interceptor_pos)) + i;
-                ip[0] = ipos.x; ip[(size_t)n] = ipos.y; ip[2 * (size_t)n] = ipos.z;
-            }
-            if (HOT(opt.info.missile_pos)) {
-                auto mp = G(HOT(opt.info.missile_pos)) + i;
-                mp[0] = mpos.x; mp[(size_t)n] = mpos.y; mp[2 * (size_t)n] = mpos.z;
-            }
-            if (HOT(opt.info.steps)) G(HOT(opt.info.steps))[i] = steps;
-            if (HOT(opt.info.missiles)) {                                                 // :846-847
-                int remaining = intercepted ? 0 : 1, got = intercepted ? 1 : 0;
-                if (HAS(HLX_F_VOLLEY)) {
-                    remaining = 0; got = n_int;
-#pragma unroll
-                    for (int k = 0; k < HLX_MAX_VOLLEY; ++k) remaining += (k < VK && vact[k]) ? 1 : 0;
+                if (RARE(!(slots & (1u << 23)))) {     // separate planes (an `if` of its own behind RARE(), not an `else`: the block then sits out of line)
+                    if (HOT(opt.info.distance)) G(HOT(opt.info.distance))[i] = distance;
+                    if (HOT(opt.info.min_distance)) G(HOT(opt.info.min_distance))[i] = min_distance;
+                    if (HOT(opt.info.fuel)) G(HOT(opt.info.fuel))[i] = fuel;
+                    if (HOT(opt.info.fuel_used)) G(HOT(opt.info.fuel_used))[i] = fuel_used;    // :834, :886
+                    if (HOT(opt.info.interceptor_pos)) {                                  // :836-838 (post-step, pre-respawn values)
+                        auto ip = G(HOT(opt.info.interceptor_pos)) + i;
+                        ip[0] = ipos.x; ip[(size_t)n] = ipos.y; ip[2 * (size_t)n] = ipos.z;
+                    }
+                    if (HOT(opt.info.missile_pos)) {
+                        auto mp = G(HOT(opt.info.missile_pos)) + i;
+                        mp[0] = mpos.x; mp[(size_t)n] = mpos.y; mp[2 * (size_t)n] = mpos.z;
+                    }
+                    if (HOT(opt.info.steps)) G(HOT(opt.info.steps))[i] = steps;
+                    if (HOT(opt.info.missiles)) G(HOT(opt.info.missiles))[i] = (uint8_t)(info_word >> 8);      // :846-847
                 }
-                G(HOT(opt.info.missiles))[i] = (uint8_t)(got | (remaining << 4));
-            }
-            if (HAS(HLX_F_VOLLEY) && HOT(opt.info.missile_min_distances)) {               // :848
-                auto md = G(HOT(opt.info.missile_min_distances)) + i;
+                if (HAS(HLX_F_VOLLEY) && HOT(opt.info.missile_min_distances)) {               // :848
+                    auto md = G(HOT(opt.info.missile_min_distances)) + i;
 #pragma unroll
-                for (int k = 0; k < HLX_MAX_VOLLEY; ++k) if (k < VK) md[(size_t)k * (size_t)n] = vmin[k];
-            }
-#if HLX_INFO_FAST
-            }
-#endif
+                    for (int k = 0; k < HLX_MAX_VOLLEY; ++k) if (k < VK) md[(size_t)k * (size_t)n] = vmin[k];
+                }
             }
         }
 #undef PIN4
@@ -1039,6 +1039,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
 #ifndef HLX_FRESH_TRIP
 #define HLX_FRESH_TRIP 1
 #endif
+        float beam_cb = 2.f;      // MODE 2: the beam-test cosine of the entry's first observation (2 = the test was not reached)
         auto trip = [&](auto all_fresh_tag) __attribute__((always_inline)) {
             constexpr bool ALLF = decltype(all_fresh_tag)::value;
             STAMP2(1);  // close-up: loop top
@@ -1082,6 +1083,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                         // other, and a copy fetched at the end of the pass measured slower than computing -- 16.2 against 15.9 us at
                         // 131 072 environments.  The host sets bit 24 for the lone-wave schedule only.)
                         if (POOL_PRE) hit = LONE ? hit_pf : false;
+                        if (LONE && hit) {
+                            // The one curriculum scalar the reference really ramps (config.yaml:85-92: the beam width, 120 -> 60 degrees over
+                            // 3 M steps, moved by EVERY call of set_training_step_count) enters a first observation through one decision:
+                            // cosine of the off-boresight angle against the threshold.  The entry carries that cosine and the threshold it
+                            // was compared with; it is the first observation under TODAY's threshold too iff both comparisons fall on
+                            // the same side, by more than the margin inside which the decision replays the reference's arithmetic.
+                            // (A new episode looks straight at its missile -- cosine 1 -- so a beam ramp invalidates next to nothing; rounds
+                            // before this one renewed ALL entries, a 12-45 us launch, ahead of every step of the ramp.)
+                            const float cbe = acc_read(pf[PG_ROW + (HLX_OBS_DIM + 3) / 4 - 1].z), cte = acc_read(pf[PG_ROW + (HLX_OBS_DIM + 3) / 4 - 1].w);
+                            const float ctn = HOT(cur.cos_half_beam);
+                            hit = (cbe - ctn > 1e-5f && cbe - cte > 1e-5f) || (ctn - cbe > 1e-5f && cte - cbe > 1e-5f);
+                        }
                         (void)tag;
                         if (MODE == 2 && (slots & (1u << 25)) != 0u && tag == epn) done = false;    // renewed since (a fill of every entry)
                     }
@@ -1293,7 +1306,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                         if (HOT(c.o_delay) > 0)                                          // :289-297
                             on_delay = min(10, max(1, (int)(3.0 * mult(COLD(dr_var[4]), zs))));
                     }
-                    steps = 0; ep_return = 0.f;                                     // :565-566
+                    steps = 0; ep_return = 0.f; fuel_used = 0.f;                    // :565-566
                     kf_init = false; kf_x64 = false;                                // core.py:65-69
                     kxp = d3(0., 0., 0.); kxv = kxp;
                     p_pp = 1000.f; p_pv = 0.f; p_vp = 0.f; p_vv = 1000.f;
@@ -1324,7 +1337,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                             crossed = (pk >> 25) & 1u; kf_init = (pk >> 26) & 1u; kf_x64 = (pk >> 27) & 1u;
                             on_delay = (int)(pk >> 28);
                         }
-                        ep_return = w1.w;
+                        ep_return = w1.w; fuel_used = 0.f;
                         kxp = d3(dbl(k0.x, k0.y), dbl(k0.z, k0.w), dbl(k1.x, k1.y));
                         kxv = d3(dbl(k1.z, k1.w), dbl(k2.x, k2.y), dbl(k2.z, k2.w));
                         p_pp = kp.x; p_pv = kp.y; p_vp = kp.z; p_vv = kp.w;
@@ -1386,6 +1399,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     const float cthr = HOT(cur.cos_half_beam);
                     float cb = clampf(fdot(fwd, rel) * __builtin_amdgcn_rcpf(range + 1e-6f), -1.f, 1.f);
                     if (RARE(on_det && fabsf(cb - cthr) < 1e-5f)) cb = clampf(sdot3(forward_vec_exact(q), rel / (range + 1e-6f)), -1.f, 1.f);
+                    // (a pool entry remembers what this test saw: a beam-width curriculum that moves the threshold leaves the entry
+                    // valid as long as the decision is the same on both sides of the move -- see "hit" in the respawn block)
+                    if (MODE == 2) beam_cb = on_det ? cb : 2.f;
                     if (on_det && cb < cthr) { on_det = false; on_why = -2.f; }
                 }
                 STAMP2(5);  // close-up: beam angle (acosf)
@@ -1714,6 +1730,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             ++pass;
         };
         trip(std::false_type{});
+        // hlx_info_soa.packed word 2: the missile as the step left it (a respawn in the second trip replaces it) + the flag word,
+        // complete now that pass 0 has decided the detections
+        if (MODE == 0 && HLX_INFO_W2 == 0 && (slots & (1u << 23)) != 0u)
+            wt16i(rsI, (uint32_t)i * 16u, (uint32_t)n * 32u, make_float4(mpos.x, mpos.y, mpos.z, __uint_as_float(info_word | det_bits)));
 #if HLX_FRESH_TRIP
         if (RARE(again)) trip(std::true_type{});
 #else
@@ -1735,7 +1755,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             PUT4(G_MPOS, g_mpos, make_float4(mpos.x, mpos.y, mpos.z, min_distance));
             PUT4(G_MVEL, g_mvel, make_float4(mvel.x, mvel.y, mvel.z, last_distance));
             PUT2(G_W0, g_w0, make_double2(wind.x, wind.y));
+            if (PERSIST) g_fu = fuel_used; else if (!HLX_AB_AUX_LATE) STAUX(fuel_used);
             }
+            if (HLX_AB_AUX_LATE && !PERSIST) STAUX(fuel_used);
             if (HAS(HLX_F_THRUST_LAG) || HAS(HLX_F_DOMAIN_RAND)) PUT4(G_THRUST, g_thr, make_float4(thrust_act.x, thrust_act.y, thrust_act.z, dp.cd_super));
             if (!((HLX_EARLY_MORE & 2) && EARLY_ST) || RARE(done)) {
             PUT4(G_W1, g_w1, make_float4(__int_as_float(__double2loint(wind.z)), __int_as_float(__double2hiint(wind.z)),
@@ -1766,9 +1788,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 pool_put(PA2, PG_GR + 1, make_float4(__int_as_float(__double2loint(g_sp.z)), __int_as_float(__double2hiint(g_sp.z)), g_sq, g_sflag));
                 pool_put(PA2, PG_GR + 2, g_s2);
 #pragma unroll
-                for (int k = 0; k < (HLX_OBS_DIM + 3) / 4; ++k)
-                    pool_put(PA2, PG_ROW + k, make_float4(row[4 * k], row[4 * k + 1], 4 * k + 2 < HLX_OBS_DIM ? row[4 * k + 2] : 0.f,
-                                                         4 * k + 3 < HLX_OBS_DIM ? row[4 * k + 3] : 0.f));
+                for (int k = 0; k < (HLX_OBS_DIM + 3) / 4; ++k)      // (the two floats behind the 26-float row: the beam test's cosine and threshold)
+                    pool_put(PA2, PG_ROW + k, make_float4(row[4 * k], row[4 * k + 1], 4 * k + 2 < HLX_OBS_DIM ? row[4 * k + 2] : beam_cb,
+                                                         4 * k + 3 < HLX_OBS_DIM ? row[4 * k + 3] : HOT(cur.cos_half_beam)));
                 G(pp2.tag)[i] = pool_epn;
             }
             const uint32_t blk_bytes = (uint32_t)min(64, n - (int)blockIdx.x * 64) * 16u;   // partial tail block: clip
@@ -1787,24 +1809,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             }
         }
         if (MODE == 0) {
-            if ((slots & (1u << 20)) && HOT(opt.info.flags))
-                G(HOT(opt.info.flags))[i] = (uint8_t)((intercepted ? 1u : 0u) | (hit_target ? 2u : 0u) | (fuze ? 4u : 0u) |
-                                            (clamped ? 8u : 0u) | (crossed ? 16u : 0u) | det_bits);
+            if (RARE((slots & (1u << 20)) && !(slots & (1u << 23))) && HOT(opt.info.flags))
+                G(HOT(opt.info.flags))[i] = (uint8_t)(info_word | det_bits);
+            if (HLX_INFO_W2 == 1 && (slots & (1u << 23)) != 0u)      // the flag dword of word 2 once more, detection bits included
+                __builtin_amdgcn_raw_buffer_store_b32(info_word | det_bits, rsI, (uint32_t)i * 16u + 12u, (uint32_t)n * 32u, HLX_INFO_AUX);
         }
         }   // if (live)
     }
 
     STAMP(14);      // state / ring / scalar outputs stored
+#define HLX_COMPACTION_BLOCK \
+        if (MODE == 0 && !PERSIST && done_idx_out) { \
+            const unsigned long long m = __ballot(live && done); \
+            if (m) { \
+                int base = 0; \
+                if (lane == 0) base = __hip_atomic_fetch_add(G(P->done_cnt) + (int)(t & 1ull), __popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                base = __shfl(base, 0); \
+                if (live && done) G(done_idx_out)[base + __popcll(m & ((1ull << lane) - 1ull))] = i; \
+            } \
+        } \
+
     // -------------------------------------------------------------------------- done-mask compaction
-    if (MODE == 0 && !PERSIST && done_idx_out) {
-        const unsigned long long m = __ballot(live && done);
-        if (m) {
-            int base = 0;
-            if (lane == 0) base = __hip_atomic_fetch_add(G(P->done_cnt) + (int)(t & 1ull), __popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            base = __shfl(base, 0);
-            if (live && done) G(done_idx_out)[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
-        }
-    }
+    if (!HLX_DONE_LATE) { HLX_COMPACTION_BLOCK }
     // Every step launch arms the counter of the NEXT vec step, whether or not this one compacts: listed and unlisted
     // steps (hlx_step without done_idx, hlx_rollout, the fused rollout) may interleave freely.
     if (MODE == 0 && !PERSIST && blockIdx.x == 0 && lane == 0) G(P->done_cnt)[(int)((t + 1ull) & 1ull)] = 0;
@@ -1870,6 +1896,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             for (int k = 0; k < HLX_OBS_DIM; ++k) dst[lane * HLX_OBS_DIM + k] = row[k];
         }
     }
+    if (HLX_DONE_LATE) { HLX_COMPACTION_BLOCK }
     STAMP(15);      // observation tile stored
     if (PERSIST) {   // next step of the fused rollout: clock, ring slots (mod their capacities), I/O cursors
         t += 1ull;
@@ -1887,7 +1914,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
     if (PERSIST && blockIdx.x == 0 && lane == 0) { G(P->done_cnt)[0] = 0; G(P->done_cnt)[1] = 0; }   // nothing was listed in this launch
     if (PERSIST && live) {   // state back to the arena, once
         STG(G_IPOS, g_ipos); STG(G_IVEL, g_ivel); STG(G_QUAT, g_quat); STG(G_MPOS, g_mpos); STG(G_MVEL, g_mvel);
-        STG(G_W0, g_w0); STG(G_W1, g_w1);
+        STG(G_W0, g_w0); STG(G_W1, g_w1); STAUX(g_fu);
         if (HAS(HLX_F_THRUST_LAG) || HAS(HLX_F_DOMAIN_RAND)) STG(G_THRUST, g_thr);
         STG(G_KF0, g_kf0); STG(G_KF1, g_kf1); STG(G_KF2, g_kf2); STG(G_KFP, g_kfp);
         if (HAS(HLX_F_DOMAIN_RAND)) STG(G_MISC, g_misc);

@@ -225,9 +225,10 @@ class HlynrVecEnv(_SB3VecEnv):
         # them to the host with a single copy instead of a dozen.
         f32, u8, i32 = torch.float32, torch.uint8, torch.int32
         _NP_DTYPES.update({f32: np.float32, u8: np.uint8, i32: np.int32})
+        # hlx_info_soa.packed (include/hlx.h): the nine standard info keys as three 16-byte words per environment -- what the
+        # step kernel stores with three coalesced instructions; the keys below are strided VIEWS of it
         spec = [("reward", f32, (n,)), ("terminated", u8, (n,)), ("truncated", u8, (n,)), ("n_done", i32, (2,)),
-                ("distance", f32, (n,)), ("min_distance", f32, (n,)), ("fuel", f32, (n,)), ("fuel_used", f32, (n,)), ("flags", u8, (n,)),
-                ("missiles", u8, (n,)), ("interceptor_pos", f32, (3, n)), ("missile_pos", f32, (3, n)), ("steps", i32, (n,))]
+                ("packed", f32, (3, n, 4))]
         if self.rc.volley_mode:
             spec.append(("missile_min_distances", f32, (_lib.MAX_VOLLEY, n)))
         if radar_debug:
@@ -250,27 +251,33 @@ class HlynrVecEnv(_SB3VecEnv):
         _lib.check(self._lib.hlx_set_done_counter(self._h, self._n_done2.data_ptr()))
         self.terminal_obs = torch.zeros((n, _lib.OBS_DIM), dtype=torch.float32, device=dev)
         self.done_idx = torch.zeros(n, dtype=torch.int32, device=dev)
-        self.info = dict(distance=v["distance"], min_distance=v["min_distance"], fuel=v["fuel"], flags=v["flags"],
-                         episode_return=torch.zeros(n, device=dev),
-                         episode_length=torch.zeros(n, dtype=torch.int32, device=dev),
-                         missiles=v["missiles"], interceptor_pos=v["interceptor_pos"], missile_pos=v["missile_pos"],
-                         steps=v["steps"], fuel_used=v["fuel_used"])
+        pk = self.info_packed = v["packed"]
+        self.info = dict(episode_return=torch.zeros(n, device=dev), episode_length=torch.zeros(n, dtype=torch.int32, device=dev),
+                         **self._unpack_info(pk, pk.view(i32), pk.view(u8)))
         if self.rc.volley_mode:
             self.info["missile_min_distances"] = v["missile_min_distances"]
         if radar_debug:
             self.info["radar_debug"] = v["radar_debug"]
-        self._info_soa = _lib.HlxInfoSoa(*(self.info[k].data_ptr() for k in
-                                           ("distance", "min_distance", "fuel", "flags", "episode_return",
-                                            "episode_length", "missiles", "interceptor_pos", "missile_pos", "steps")),
-                                         self.info["missile_min_distances"].data_ptr() if self.rc.volley_mode else None,
-                                         self.info["radar_debug"].data_ptr() if radar_debug else None,
-                                         self.info["fuel_used"].data_ptr())
+        self._info_soa = _lib.HlxInfoSoa(episode_return=self.info["episode_return"].data_ptr(),
+                                         episode_length=self.info["episode_length"].data_ptr(),
+                                         missile_min_distances=self.info["missile_min_distances"].data_ptr() if self.rc.volley_mode else None,
+                                         radar_debug=self.info["radar_debug"].data_ptr() if radar_debug else None,
+                                         packed=pk.data_ptr())
         self._info_ref = C.byref(self._info_soa)
         self._ptr_done_idx = self.done_idx.data_ptr()
         self._step_ptrs = (self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(), self.truncated.data_ptr(),
                            self.terminal_obs.data_ptr())
         self._actions_dev = torch.zeros((n, _lib.ACT_DIM), dtype=torch.float32, device=dev)
         self._actions_pin = torch.zeros((n, _lib.ACT_DIM), dtype=torch.float32, pin_memory=True)
+
+    @staticmethod
+    def _unpack_info(pk, pk_i32, pk_u8):
+        """The reference's info keys (environment.py:829-857) as views of hlx_info_soa.packed [3, N, 4] (float32, and the same
+        bytes seen as int32 / as uint8 [3, N, 16]); works on torch tensors and numpy arrays alike.  Word 2's last dword:
+        byte 0 = the flag bits (hlx.h), byte 1 = missiles intercepted / remaining nibbles."""
+        return dict(distance=pk[0, :, 0], min_distance=pk[0, :, 1], fuel=pk[0, :, 2], fuel_used=pk[0, :, 3],
+                    interceptor_pos=pk[1, :, 0:3].T, steps=pk_i32[1, :, 3], missile_pos=pk[2, :, 0:3].T,
+                    flags=pk_u8[2, :, 12], missiles=pk_u8[2, :, 13])
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -415,6 +422,11 @@ class HlynrVecEnv(_SB3VecEnv):
 
     def _materialise(self, obs, rew, term, trunc, info, terminal):
         """Device step results -> the numpy (obs, rewards, dones, infos) tuple SB3 expects (one D2H copy each)."""
+        return self._materialise_end(self._materialise_begin(obs, rew, term, trunc, info, terminal))
+
+    def _materialise_begin(self, obs, rew, term, trunc, info, terminal):
+        """Enqueue the device-to-host copies of one step's results on the current stream; nothing is waited for (a caller
+        with several devices -- sharded.py -- has every shard's copies in flight before it waits for the first)."""
         torch = self._torch
 
         def d2h(t):   # pinned staging (torch's caching host allocator recycles the blocks), all copies in flight at once
@@ -427,7 +439,11 @@ class HlynrVecEnv(_SB3VecEnv):
         slab_h, obs_t = d2h(self._slab), d2h(obs)
         own = {name: d2h(t) for name, t, mine in (("reward", rew, self.reward), ("terminated", term, self.terminated),
                                                    ("truncated", trunc, self.truncated)) if t.data_ptr() != mine.data_ptr()}
-        torch.cuda.current_stream(self.device).synchronize()
+        return slab_h, obs_t, own, terminal, torch.cuda.current_stream(self.device), int(self._lib.hlx_vec_steps(self._h)) & 1
+
+    def _materialise_end(self, ticket):
+        slab_h, obs_t, own, terminal, stream, parity = ticket
+        stream.synchronize()
         slab_np = slab_h.numpy()
 
         def plane(name):
@@ -439,22 +455,23 @@ class HlynrVecEnv(_SB3VecEnv):
         obs_h, rew_h = obs_t.numpy(), plane("reward")
         term_h, trunc_h = plane("terminated").astype(bool), plane("truncated").astype(bool)
         dones = term_h | trunc_h
-        n_done = int(plane("n_done")[int(self._lib.hlx_vec_steps(self._h)) & 1])
+        n_done = int(plane("n_done")[parity])
         host = dict(terminated=term_h, truncated=trunc_h, t_start=self._t_start, radar_quality=self.rc.radar_quality,
                     volley=(bool(self.rc.volley_mode), int(self.rc.volley_size) if self.rc.volley_mode else 1))
-        for k in ("distance", "min_distance", "fuel", "fuel_used", "flags", "missiles", "interceptor_pos", "missile_pos", "steps"):
-            host[k] = plane(k)
+        pk = plane("packed")
+        host.update(self._unpack_info(pk, pk.view(np.int32), pk.view(np.uint8)))
         if "missile_min_distances" in self._slab_layout:
             host["missile_min_distances"] = plane("missile_min_distances")
         if "radar_debug" in self._slab_layout:
             host["radar"] = dict(planes=plane("radar_debug"), rc=self.rc, beam_width=self.curriculum()["beam_width"])
         done_rows: Dict[int, int] = {}
         if n_done:
-            idx = self.done_idx[:n_done].to(self._torch.int64)
-            idx_h = idx.cpu().numpy()
-            host["terminal_obs"] = terminal.index_select(0, idx).cpu().numpy()
-            host["ep_return"] = self.info["episode_return"].index_select(0, idx).cpu().numpy()
-            host["ep_length"] = self.info["episode_length"].index_select(0, idx).cpu().numpy()
+            with self._torch.cuda.stream(stream):
+                idx = self.done_idx[:n_done].to(self._torch.int64)
+                idx_h = idx.cpu().numpy()
+                host["terminal_obs"] = terminal.index_select(0, idx).cpu().numpy()
+                host["ep_return"] = self.info["episode_return"].index_select(0, idx).cpu().numpy()
+                host["ep_length"] = self.info["episode_length"].index_select(0, idx).cpu().numpy()
             done_rows = {int(e): r for r, e in enumerate(idx_h)}
         return obs_h, rew_h, dones, LazyInfos(self.num_envs, done_rows, host)
 
@@ -485,6 +502,12 @@ class HlynrVecEnv(_SB3VecEnv):
         out = C.c_int64(0)
         _lib.check(self._lib.hlx_get_episode_pool_misses(self._h, C.byref(out)))
         return int(out.value)
+
+    def episode_pool_stats(self) -> Dict[str, int]:
+        """{misses, full_fills, partial_fills, suspended_steps} of the next-episode pool (hlx.h; synchronises)."""
+        out = (C.c_int64 * 4)()
+        _lib.check(self._lib.hlx_get_episode_pool_stats(self._h, C.byref(out)))
+        return dict(misses=int(out[0]), full_fills=int(out[1]), partial_fills=int(out[2]), suspended_steps=int(out[3]))
 
     def set_load_schedule(self, mode: int):
         """-1 auto (by batch size), 0 all loads at kernel entry, 1 Kalman / ring loads behind the Philox block, 2 = 1 + the

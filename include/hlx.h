@@ -144,12 +144,22 @@ typedef struct hlx_info_soa {
                                      of this step).  Requires HLX_F_RADAR_DEBUG (hlx_step fails otherwise).
                                      hlynr_intercept_amd/episode_log.py assembles the dict. */
     float *fuel_used;         /* [N] info['fuel_used'] = the reference's `total_fuel_used` (environment.py:204, 566, 834, 886):
-                                     the float32 running sum of the fuel each step of the episode consumed.  The plane is an
-                                     ACCUMULATOR that lives in the caller's buffer: a step reads the previous value, adds this
-                                     step's consumption and writes it back (the first step of an episode starts from 0 without
-                                     reading), so the value is the reference's, bit for bit, as long as the SAME buffer is
-                                     passed at every step of the episode and nothing else writes it.  4 B read + 4 B written
-                                     per environment and step instead of a 16-byte state group on every launch. */
+                                     the float32 running sum of the fuel each step of the episode consumed.  The sum is
+                                     ENVIRONMENT STATE (hlx_env_state.fuel_used: it lives in the library's arena, travels through
+                                     hlx_get_state / hlx_set_state, and advances in every form of the step -- fused and
+                                     non-contract rollouts included); this plane receives a copy. */
+    float *packed;            /* [3][N][4] dwords -- the nine standard keys above in three 16-byte words per environment, the
+                                     layout the step kernel can store with three coalesced 16-byte-per-lane instructions (1 KiB per
+                                     wave each) instead of eleven 4-byte and two 1-byte ones:
+                                       word 0 [N]: distance, min_distance, fuel (= info['fuel_remaining']), fuel_used      (float32)
+                                       word 1 [N]: interceptor_pos x, y, z (float32), steps (int32 bit pattern)
+                                       word 2 [N]: missile_pos x, y, z (float32), one uint32: bits 0-7 = `flags` as above,
+                                                   bits 8-15 = `missiles` as above, bit 16 terminated, bit 17 truncated
+                                     When `packed` is given, distance / min_distance / fuel / fuel_used / flags / missiles /
+                                     interceptor_pos / missile_pos / steps above must be NULL (hlx_step fails otherwise); the
+                                     finished-environment planes (episode_return, episode_length), missile_min_distances and
+                                     radar_debug stay separate.  hlynr_intercept_amd.HlynrVecEnv exposes the same info[...] keys
+                                     as strided views of this buffer. */
 } hlx_info_soa;
 
 /* Logical per-environment state, array-of-struct, HOST memory: parity injection and checkpointing. */
@@ -184,6 +194,9 @@ typedef struct hlx_env_state {
     float v_min[HLX_MAX_VOLLEY];        /* missile_min_distances */
     int32_t v_active[HLX_MAX_VOLLEY];
     int32_t prio, n_intercepted;
+    float fuel_used;                    /* the reference's `total_fuel_used` (environment.py:204, 566, 886): float32 running sum of the
+                                           episode's fuel consumption, 0 at every reset; info['fuel_used'] reports it */
+    int32_t pad2;
 } hlx_env_state;
 
 typedef struct hlx_env hlx_env;
@@ -295,8 +308,8 @@ int hlx_profile_read(hlx_env *env, double *total_ms, int64_t *launches);
  * work), and a finished environment copies its entry inside the step launch instead of computing it there -- which is what
  * used to keep every step launch open.  An environment that finishes again before its entry has been renewed computes it
  * on the spot: same draws, same arithmetic, same bits; the pool changes when work is done, never a result.  hlx_reset,
- * hlx_set_seed (which restarts k), hlx_set_state and a curriculum update that moves the radar beam width or a sensor
- * reliability renew every entry before the next step launch.  interval: > 0 step launches between fills, 0 = no pool,
+ * hlx_set_seed (which restarts k) and hlx_set_state renew every entry before the next step launch; for curriculum updates see
+ * hlx_get_episode_pool_stats below.  interval: > 0 step launches between fills, 0 = no pool,
  * -1 = the default (128).  hlx_get_episode_pool returns the interval in force (0 = off).  Prepared episodes are used by the
  * lone-wave load schedule only (hlx_set_load_schedule 2: batches of at most one wave per SIMD, where the stragglers of a launch
  * are exposed); under the other schedules every auto-reset is computed in place, from the same draws, and no fill is launched.
@@ -304,6 +317,15 @@ int hlx_profile_read(hlx_env *env, double *total_ms, int64_t *launches);
 int hlx_set_episode_pool(hlx_env *env, int32_t interval);
 int32_t hlx_get_episode_pool(const hlx_env *env);
 int hlx_get_episode_pool_misses(hlx_env *env, int64_t *misses);
+/* The pool under a moving curriculum (environment.py:274-351; the reference's trainers call set_training_step_count after EVERY
+ * step, train_flat_ppo.py:171-177).  A first observation reads three curriculum scalars.  The radar BEAM WIDTH -- the one the
+ * shipped curriculum ramps (config.yaml:85-92) -- costs nothing: every prepared episode remembers the beam test it was computed
+ * with and is used only if today's threshold decides it the same way (a new episode looks straight at its missile, so a ramp
+ * invalidates next to nothing).  A sensor RELIABILITY that moves makes every prepared episode stale: while one is moving the pool
+ * is suspended (next episodes are computed in place, as without a pool) and is filled again once the scalars have stood still
+ * for 16 step launches.  out[4] = {auto-resets computed inside step launches with the pool in use, full fills, partial fills,
+ * step launches issued while the pool was suspended} (synchronises; diagnostics). */
+int hlx_get_episode_pool_stats(hlx_env *env, int64_t out[4]);
 
 /* Load schedule of the step kernel (three instantiations of the same source, bit-identical results): 1 = the Kalman
  * groups and the delayed ground-ring sample are loaded as a second batch behind the Philox block (best while a SIMD
@@ -332,6 +354,11 @@ const char *hlx_kernel_baked(const hlx_env *env);
 const char *hlx_kernel_variant(const hlx_env *env);     /* "base", "v2", "v2dr", "config", "config-easy", "config-volley", "generic" or "generic-volley" */
 int32_t hlx_sizeof_config(void);
 int32_t hlx_sizeof_env_state(void);
+int32_t hlx_sizeof_info_soa(void);
+/* ABI revision of this header (HLX_ABI_VERSION): bumped whenever a struct grows or an entry point changes meaning, so that a
+ * binding can refuse a library built from another revision even where it cannot rebuild it (hlynr_intercept_amd/_lib.py). */
+#define HLX_ABI_VERSION 4
+int32_t hlx_abi_version(void);
 const char *hlx_last_error(void);
 const char *hlx_version(void);
 

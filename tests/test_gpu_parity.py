@@ -67,6 +67,7 @@ def _oracle_to_gpu_state(ora, env):
             for k in range(len(dst)):
                 dst[k] = src[k]
         g.fuel, g.prev_distance, g.min_distance, g.last_distance = o.fuel, o.prev_distance, o.min_distance, o.last_distance
+        g.fuel_used = o.total_fuel_used                    # environment.py:886 (float32-valued in the oracle's double)
         g.steps, g.worsening, g.crossed, g.kf_init, g.kf_x_is64 = o.steps, o.worsening, o.crossed, o.kf_init, o.kf_x_is64
         g.kf_P[0], g.kf_P[1], g.kf_P[2], g.kf_P[3] = o.kf_P[0], o.kf_P[3], o.kf_P[18], o.kf_P[21]
         g.on_delay, g.on_len = o.on_delay, o.on_len
@@ -241,6 +242,10 @@ def _replay_fixture(name, radar):
             assert np.max(_rel(info["interceptor_pos"].cpu().numpy()[:, 0], fx["st_int_pos"][j])) <= 2 * RTOL, t
             assert np.max(_rel(info["missile_pos"].cpu().numpy()[:, 0], fx["st_mis_pos"][j])) <= 2 * RTOL, t
             assert int(info["steps"][0]) == int(fx["st_steps"][j]), t
+            # info['crossed_threshold'] (environment.py:851) as the step leaves it -- also on the step that ends the episode
+            # (until round 3 a finished environment reported the flag of its NEXT episode, i.e. always False)
+            assert np.all(((flags >> 4) & 1) == int(fx["st_crossed"][j])), (t, flags, int(fx["st_crossed"][j]))
+            assert np.max(_rel(info["min_distance"].cpu().numpy()[0], fx["st_min_distance"][j])) <= RTOL, t
         if fx["did_reset"][t]:
             worst["reset_obs"] = max(worst["reset_obs"], float(np.max(_obs_err(obs_h, fx["reset_obs"][k_reset][None]))))
             k_reset += 1

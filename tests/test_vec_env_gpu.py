@@ -687,3 +687,142 @@ def test_next_episode_pool_changes_when_work_is_done_never_a_result(physics, ove
     assert bytes(a.get_state()) == bytes(b.get_state()) == bytes(c.get_state())
     for e in envs + [a, b, c]:
         e.close()
+
+
+def test_fuel_used_is_environment_state_in_every_form_of_the_step():
+    """`total_fuel_used` (environment.py:204, 566, 886) lives in the arena (hlx_env_state.fuel_used), not in a caller plane
+    (round-3 advisor finding): it survives get_state -> set_state mid-episode, and it advances in the forms of the step that
+    pass no info plane at all -- fused rollouts and plain rollouts -- so that the next step_torch reports the reference's
+    running sum, bit for bit the one an uninterrupted step_torch run reports."""
+    import torch
+    n, T = 300, 40
+    over = {"max_steps": 29}
+    ref, a, b, c = (_env(n, physics="v2", over=over, seed=5) for _ in range(4))
+    g = torch.Generator(device=ref.device).manual_seed(3)
+    tape = torch.rand((T + 1, n, 6), generator=g, device=ref.device) * 2 - 1
+    for e in (ref, a, b, c):
+        e.reset_torch()
+    want = None
+    for t in range(T + 1):
+        want = [x.clone() for x in ref.step_torch(tape[t])[:4]] + [ref.info[k].clone() for k in ("fuel_used", "fuel", "steps", "flags")]
+    want_state = bytes(ref.get_state())
+    # (a) checkpoint in the middle of the episodes: export, overwrite the arena with another run's state, restore, go on
+    for t in range(T // 2):
+        a.step_torch(tape[t])
+    snap = a.get_state()
+    assert any(s.fuel_used > 0 for s in snap) and all(abs((100.0 - s.fuel) - s.fuel_used) < 2e-3 for s in snap)
+    for t in range(7):
+        a.step_torch(tape[t])                                   # wander off ...
+    a.set_state(snap)                                           # ... and come back: the clock has moved, so only the state is compared
+    st = a.get_state()
+    assert [s.fuel_used for s in st] == [s.fuel_used for s in snap]
+    # (b) T steps as ONE fused rollout (no info plane, state in registers), then a step that reports
+    b.set_rollout_fused(16)
+    b.rollout_torch(tape[:T].contiguous(), 4)
+    b.set_rollout_fused(1)
+    # (c) T steps as a plain rollout without the contract outputs (no info plane), then a step that reports
+    c.rollout_torch(tape[:T].contiguous(), 4)
+    for e in (b, c):
+        got = [x.clone() for x in e.step_torch(tape[T])[:4]] + [e.info[k].clone() for k in ("fuel_used", "fuel", "steps", "flags")]
+        for x, y in zip(want, got):
+            assert torch.equal(x, y)
+        assert bytes(e.get_state()) == want_state
+    for e in (ref, a, b, c):
+        e.close()
+
+
+def test_packed_info_words_equal_the_separate_planes_and_exclude_them():
+    """hlx_info_soa.packed (three 16-byte words per environment) against the nine separate planes of the same C ABI: same
+    values, bit for bit, every step across auto-resets, volley mode included; both at once are refused."""
+    import ctypes as C
+    import torch
+    from hlynr_intercept_amd import _lib as hl
+    for physics, over in (("base", {"max_steps": 21}), ("config", {"max_steps": 21, "volley_mode": True, "volley_size": 3})):
+        n, T = 200, 50
+        a, b = _env(n, physics=physics, over=over, seed=11), _env(n, physics=physics, over=over, seed=11)
+        dev = a.device
+        sep = dict(distance=torch.zeros(n, device=dev), min_distance=torch.zeros(n, device=dev), fuel=torch.zeros(n, device=dev),
+                   fuel_used=torch.zeros(n, device=dev), flags=torch.zeros(n, dtype=torch.uint8, device=dev),
+                   missiles=torch.zeros(n, dtype=torch.uint8, device=dev), interceptor_pos=torch.zeros((3, n), device=dev),
+                   missile_pos=torch.zeros((3, n), device=dev), steps=torch.zeros(n, dtype=torch.int32, device=dev))
+        soa = hl.HlxInfoSoa(episode_return=b.info["episode_return"].data_ptr(), episode_length=b.info["episode_length"].data_ptr(),
+                            **{k: v.data_ptr() for k, v in sep.items()})
+        both = hl.HlxInfoSoa(packed=b.info_packed.data_ptr(), distance=sep["distance"].data_ptr())
+        a.reset_torch(); b.reset_torch()
+        g = torch.Generator(device=dev).manual_seed(1)
+        p = b._step_ptrs
+        act0 = torch.zeros((n, 6), device=dev)
+        rc = b._lib.hlx_step(b._h, act0.data_ptr(), p[0], p[1], p[2], p[3], p[4], None, None, C.byref(both), b._stream())
+        assert rc == -1 and b"packed" in b._lib.hlx_last_error()
+        dones = 0
+        for t in range(T):
+            act = torch.rand((n, 6), generator=g, device=dev) * 2 - 1
+            obs, rew, term, trunc, info = a.step_torch(act)
+            hl.check(b._lib.hlx_step(b._h, act.data_ptr(), p[0], p[1], p[2], p[3], p[4], None, None, C.byref(soa), b._stream()))
+            assert torch.equal(obs, b.obs) and torch.equal(rew, b.reward) and torch.equal(term, b.terminated)
+            for k, v in sep.items():
+                assert torch.equal(info[k], v), (physics, t, k)
+            word = a.info_packed.view(torch.int32)[2, :, 3]
+            assert torch.equal((word >> 16) & 1, term.to(torch.int32)) and torch.equal((word >> 17) & 1, trunc.to(torch.int32))
+            done = (term | trunc) != 0
+            dones += int(done.sum())
+            for k in ("episode_return", "episode_length"):
+                assert torch.equal(a.info[k][done], b.info[k][done])
+        assert dones >= 2 * n
+        assert bytes(a.get_state()) == bytes(b.get_state())
+        a.close(); b.close()
+
+
+@pytest.mark.parametrize("ramp", ["beam", "reliability"])
+def test_next_episode_pool_under_a_curriculum_that_moves_every_step(ramp):
+    """The reference's trainers call set_training_step_count after EVERY step (train_flat_ppo.py:171-177) and the shipped
+    radar curriculum ramps the beam width over 3 M steps (config.yaml:85-92).  Round 3 renewed every prepared episode ahead
+    of every step of such a ramp (advisor finding).  Now: a beam ramp costs no fill at all -- entries carry the beam test they
+    were computed with and are validated against today's threshold, and a new episode looks straight at its missile -- and a
+    reliability ramp suspends the pool until the scalars have stood still for 16 steps.  Either way: same bits as no pool."""
+    import torch
+    n, T = 1300, 150
+    over = {"max_steps": 19}
+    if ramp == "reliability":
+        over.update({"curriculum.radar_curriculum.final_detection_reliability": 0.6,
+                     "curriculum.radar_curriculum.reliability_transition_start": 5_000_000,
+                     "curriculum.radar_curriculum.reliability_transition_end": 8_000_000,
+                     "curriculum.radar_curriculum.final_ground_reliability": 0.7,
+                     "curriculum.radar_curriculum.ground_reliability_transition_start": 5_000_000,
+                     "curriculum.radar_curriculum.ground_reliability_transition_end": 8_000_000})
+    on, off = _env(n, physics="base", over=over, seed=41), _env(n, physics="base", over=over, seed=41)
+    off.set_episode_pool(0)
+    on.set_episode_pool(8)            # (episodes last 19 steps here: with a fill every 8 steps no environment finishes twice between two fills)
+    assert on.load_schedule == 2 and on.episode_pool == 8
+    for e in (on, off):
+        e.set_training_step_count(4_990_000)
+        e.reset_torch()
+    g = torch.Generator(device=on.device).manual_seed(6)
+    moved = set()
+    for t in range(T):
+        a = torch.rand((n, 6), generator=g, device=on.device) * 2 - 1
+        # ~76 steps inside the ramp 5 M -> 8 M (the scalars move at every step), then they stand still at its end
+        step = 4_990_000 + 40_000 * t if t < 100 else 9_000_000
+        outs = []
+        for e in (on, off):
+            e.set_training_step_count(step)
+            obs, rew, term, trunc, info = e.step_torch(a, want_done_list=True)
+            done = (term | trunc) != 0
+            outs.append([obs.clone(), rew.clone(), term.clone(), trunc.clone(), e.terminal_obs[done].clone(), e.info_packed.clone(),
+                         e.info["episode_return"][done].clone()])
+        for k, (x, y) in enumerate(zip(*outs)):
+            assert torch.equal(x, y), (ramp, t, k)
+        c = on.curriculum()
+        moved.add((round(c["beam_width"], 6), round(c["onboard_reliability"], 6), round(c["ground_reliability"], 6)))
+    assert len(moved) > 70                                               # the curriculum really moved at every step of the ramp
+    assert bytes(on.get_state()) == bytes(off.get_state())
+    st = on.episode_pool_stats()
+    resets = T * n // 19
+    if ramp == "beam":
+        # the initial fill, and partial fills every 128 steps: never a full fill because the beam moved; (nearly) every auto-reset was served
+        assert st["full_fills"] == 1 and st["suspended_steps"] == 0 and st["partial_fills"] >= T // 8 - 2, st
+        assert st["misses"] <= resets // 20, (st, resets)
+    else:
+        # suspended while the reliabilities moved (~76 steps + 16 quiet ones), filled once when they had settled
+        assert 70 <= st["suspended_steps"] <= 100 and st["full_fills"] == 2, st
+    on.close(); off.close()
