@@ -88,16 +88,15 @@ struct KOpt {              // optional caller buffers (re-uploaded only when the
     // observation pipeline riding on the step (hlx_obs_step, include/hlx_obs.h): the step kernel leaves, per 64-environment block,
     // the float64 column sums / sums of squares of the NEWEST frame (its own observation tile) and advances the discounted returns,
     // so that the pipeline's moments pass over the batch disappears.  NULL = no pipeline attached to this launch.
-    double* pipe_partial;        // [blocks][pipe_stride]: column c of the stacked batch at [2 c], [2 c + 1]; return sums at [stride - 4],
-                                 // [stride - 3]; the block's done mask (64-bit ballot, as a bit pattern) at [stride - 2]
+    double* pipe_partial;        // [2 D + 3][blocks]: feature f of the newest frame at rows 2 f (sum), 2 f + 1 (sum of squares); the return
+                                 // sums at rows 2 D, 2 D + 1; the block's done mask (64-bit ballot, as a bit pattern) at row 2 D + 2
     double* pipe_returns;        // [N] discounted returns (NULL: not updated this step)
     double pipe_gamma;
-    int32_t pipe_stride, pipe_col0;   // 2 F + 4 doubles per block; first column of the newest frame, (n_stack - 1) * D
+    int32_t pipe_stride, pipe_col0;   // the number of 64-environment blocks (the row length above); first column of the newest frame, (n_stack - 1) * D
 };
-struct KCur {              // curriculum scalars in force (re-uploaded when hlx_set_global_step changes them)
-    double half_beam;
-    float radius, on_rel, g_rel;
-    float cos_half_beam;   // beam test on the cosine: arccos(x) > hb <=> x < cos(hb); -2 when hb >= pi
+struct KCur {              // (until round 3: the curriculum scalars in force.  They are kernel arguments now -- hlx_kernels.hip -- and
+    double reserved0;      // this block keeps its size so that the offsets of KOpt, which the baked tables do not cover, stay put)
+    float reserved1[4];
 };
 // The hot part {c, cur, opt} is at most 512 B = 128 dwords: at kernel entry lane l loads dwords l and 64 + l
 // (two coalesced vector loads, in flight with the state loads), and every constant is then a v_readlane away --

@@ -240,6 +240,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
     // ---- ordinary kernarg tail (one scalar load, issued at entry, first needed when results are stored)
     float* __restrict__ obs_out0, float* __restrict__ reward_out0, uint8_t* __restrict__ term_out0,
     uint8_t* __restrict__ trunc_out0,
+    // ---- the curriculum scalars in force (environment.py:223-234, 274-351), evaluated by the host at hlx_set_global_step: plain
+    //      kernel arguments since round 4 -- the reference's trainers move them after EVERY step (train_flat_ppo.py:171-177), and
+    //      while they lived in the device-resident parameter block each move was a 24-byte copy command between two step launches
+    //      (+3.3 us per step through a curriculum ramp, profiles/r04_pool_curriculum_ramp.txt); in the kernarg tail they cost nothing
+    const float cur_radius, const float cur_cos_half_beam /* beam test on the cosine: arccos(x) > hb <=> x < cos(hb); -2 when hb >= pi */,
+    const float cur_on_rel, const float cur_g_rel,
     // ---- fused rollout only: steps in this launch; output slot of the first step; output slots (step k of the
     //      rollout writes slot k mod out_slots of the [out_slots][N][...] output arrays)
     const int T, const int out_slot0, const int out_slots) {
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
     // (before the state loads, so that everything below stays one block: placed behind them it split the entry block and cost the
     // base kernel 0.45 us) keeps the load in the entry block -- issued first, landed long before it is needed -- at the price of
     // one scalar compare.  profiles/r02_ab_kernarg_tail_load_pinned.txt: config presets 9.45 -> 8.65 us, base and v2dr unchanged.
-    if (RARE(n < 0)) asm volatile("" ::"s"(obs_out0), "s"(reward_out0), "s"(term_out0), "s"(trunc_out0));
+    if (RARE(n < 0)) asm volatile("" ::"s"(obs_out0), "s"(reward_out0), "s"(term_out0), "s"(trunc_out0), "s"(cur_radius), "s"(cur_cos_half_beam), "s"(cur_on_rel), "s"(cur_g_rel));
     const int lane = threadIdx.x;
     int g_rslot = (int)(slots & 15u), g_wslot = (int)((slots >> 4) & 15u), o_wslot = (int)((slots >> 8) & 15u);
     const int g_planes = (int)((slots >> 12) & 15u), o_planes = (int)((slots >> 16) & 15u);   // preloaded: no *P needed
@@ -769,7 +775,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             distance = snorm3(rel);
             range_c = distance;
             if (HAS(HLX_F_VOLLEY)) {                                                // :661-692
-                const float thr = HAS(HLX_F_PROX_FUZE) ? HOT(c.kill_radius) : HOT(cur.radius);
+                const float thr = HAS(HLX_F_PROX_FUZE) ? HOT(c.kill_radius) : cur_radius;
                 intercepted = false;
 #pragma unroll
                 for (int k = 0; k < HLX_MAX_VOLLEY; ++k) {
@@ -784,7 +790,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 for (int k = 0; k < HLX_MAX_VOLLEY; ++k)
                     if (k < VK && vact[k] && (!any || vd[k] < distance)) { distance = vd[k]; any = true; }
             } else if (HAS(HLX_F_PROX_FUZE)) intercepted = distance < HOT(c.kill_radius); // :700-703
-            else intercepted = distance < HOT(cur.radius);
+            else intercepted = distance < cur_radius;
             min_distance = (distance < min_distance) ? distance : min_distance;     // :706
             if (intercepted) crossed = true;                                        // :709-710
             if (HAS(HLX_F_PROX_FUZE) && min_distance < HOT(c.kill_radius)) { fuze = true; intercepted = true; } // :715-717
@@ -828,7 +834,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     float md = min_distance;
                     if (crossed) {
                         reward = 3000.f;
-                        if (md < HOT(cur.radius)) reward = reward + HLX_DIVF(HOT(cur.radius) - md, HOT(cur.radius)) * 1000.f;
+                        if (md < cur_radius) reward = reward + HLX_DIVF(cur_radius - md, cur_radius) * 1000.f;
                         reward = reward + exp_np(divc(-md, 1.0 / 25.0)) * 500.f;
                         reward = reward + exp_np(divc(-md, 1.0 / 10.0)) * 1000.f;
                         reward = reward + exp_np(divc(-md, 1.0 / 3.0)) * 500.f;
@@ -1092,7 +1098,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                             // (A new episode looks straight at its missile -- cosine 1 -- so a beam ramp invalidates next to nothing; rounds
                             // before this one renewed ALL entries, a 12-45 us launch, ahead of every step of the ramp.)
                             const float cbe = acc_read(pf[PG_ROW + (HLX_OBS_DIM + 3) / 4 - 1].z), cte = acc_read(pf[PG_ROW + (HLX_OBS_DIM + 3) / 4 - 1].w);
-                            const float ctn = HOT(cur.cos_half_beam);
+                            const float ctn = cur_cos_half_beam;
                             hit = (cbe - ctn > 1e-5f && cbe - cte > 1e-5f) || (ctn - cbe > 1e-5f && cte - cbe > 1e-5f);
                         }
                         (void)tag;
@@ -1384,6 +1390,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 // ======================================================== core.py:511-691 radar detection
                 STAMP2(2);  // close-up: draws selected
                 const V3 rel = mpos - ipos;
+#ifndef HLX_ONBOARD_EARLY
+#define HLX_ONBOARD_EARLY 0
+#endif
+                // The delayed onboard sample (physics v2: core.py:576-593) is a GATHER -- domain randomisation gives every lane its own
+                // delay, i.e. its own ring plane.  It is read in place, where the onboard section needs it (below).  Requesting it
+                // EARLIER has now lost twice: from the physics section behind the second load batch (round 3: +0.8 us), and from here,
+                // the top of the pass, with its registers untouched until the measurement fusion ~2 k cycles further down
+                // (-DHLX_ONBOARD_EARLY=1, round 4: v2dr contract form 11.28 -> 11.65 us, profiles/r04_ab_v2dr_onboard_gather_early.txt).
+                // A 64-line gather at the head of the in-order memory queue holds back the output, info and state stores issued
+                // right behind it; in place it follows them.
+                float4 on_raw = make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool on_have = HOT(c.o_delay) > 0 && !fresh_k && steps >= on_delay;
+                if (HLX_ONBOARD_EARLY && HOT(c.o_delay) > 0 && on_have) {
+                    int slot = o_wslot - on_delay;                            // (t - on_delay) mod o_cap
+                    slot += (slot < 0) ? o_cap : 0;
+                    on_raw = oring[(size_t)slot * N + i];
+                }
                 // ||missile - interceptor|| is at hand: the step's `distance`, or the spawn distance of a lane that has just respawned
                 const float range = (HAS(HLX_F_VOLLEY) || MODE != 0) ? snorm3(rel) : range_c;
                 bool on_det = !(range > HOT(c.radar_range));                             // :539
@@ -1396,7 +1419,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     // formed with the reference's own float32 operations, so the DECISION is the reference's, bit for bit
                     // Fast arithmetic decides unless the argument is within 1e-5 of c* (ten times the fast path's error bound):
                     // only then -- about one env-step in 1e5 -- is the reference's operation order replayed.
-                    const float cthr = HOT(cur.cos_half_beam);
+                    const float cthr = cur_cos_half_beam;
                     float cb = clampf(fdot(fwd, rel) * __builtin_amdgcn_rcpf(range + 1e-6f), -1.f, 1.f);
                     if (RARE(on_det && fabsf(cb - cthr) < 1e-5f)) cb = clampf(sdot3(forward_vec_exact(q), rel / (range + 1e-6f)), -1.f, 1.f);
                     // (a pool entry remembers what this test saw: a beam-width curriculum that moves the threshold leaves the entry
@@ -1406,9 +1429,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 }
                 STAMP2(5);  // close-up: beam angle (acosf)
                 {                                                                   // :559-566 (straight-line: selects, not a divergent block)
-                    float aq = (HOT(c.radar_quality) * (1.0f - (range * HOT(c.inv_radar_range)) * 0.5f)) * HOT(cur.on_rel);
+                    float aq = (HOT(c.radar_quality) * (1.0f - (range * HOT(c.inv_radar_range)) * 0.5f)) * cur_on_rel;
                     if (RARE(on_det && fabsf(n_on - aq) < 2e-6f))   // Bernoulli draw within a few ulps of the probability: the reference's own division
-                        aq = (HOT(c.radar_quality) * (1.0f - HLX_DIVF(range, HOT(c.radar_range)) * 0.5f)) * HOT(cur.on_rel);
+                        aq = (HOT(c.radar_quality) * (1.0f - HLX_DIVF(range, HOT(c.radar_range)) * 0.5f)) * cur_on_rel;
                     const bool miss = on_det && n_on > aq;
                     on_det = on_det && !miss;
                     on_why = miss ? -3.f : on_why;
@@ -1419,7 +1442,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 if (HOT(c.o_delay) > 0) {                                                // :576-588 onboard delay ring
                     on_sample = make_float4(rel.x, rel.y, rel.z, on_det ? 1.f : (HAS(HLX_F_RADAR_DEBUG) ? on_why : 0.f));   // w: 1 detected, -reason otherwise
                     d_on = v3(0.f, 0.f, 0.f); d_on_det = false; on_why = -4.f;              // :582 'sensor_delay_initialization'
-                    if (!fresh_k && steps >= on_delay) {
+                    if (!HLX_ONBOARD_EARLY && !fresh_k && steps >= on_delay) {
                         int slot = o_wslot - on_delay;                            // (t - on_delay) mod o_cap
                         slot += (slot < 0) ? o_cap : 0;
                         float4 s = oring[(size_t)slot * N + i];
@@ -1448,14 +1471,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                         g_det = g_det && !(chk && (se < HOT(c.sin_min_elev) || se > HOT(c.sin_max_elev)));
                     }
                     g_det = g_det && !(mpos.z < 50.f);                              // :409
-                    float dpq = ((HOT(c.g_base_q) * (1.0f - (grange * HOT(c.inv_g_max_range)) * 0.4f)) * HOT(c.weather)) * HOT(cur.g_rel);   // :413-418
+                    float dpq = ((HOT(c.g_base_q) * (1.0f - (grange * HOT(c.inv_g_max_range)) * 0.4f)) * HOT(c.weather)) * cur_g_rel;   // :413-418
                     // The reference's own operations where the Bernoulli draw is within reach of the fast value's error -- and always in
                     // los_frame mode: the quality is also the measurement's WEIGHT in the fusion below (core.py:735-738), an ulp of it is
                     // 3e-8 of the fused position, and the LOS-frame lead angle / LOS rates amplify exactly that when the velocity estimate
                     // or the range is small (found with tools/diag_kf.py: the filter state differed by 2e-8 relative from the first
                     // float64 measurement on).  Elsewhere no output shows it above 4e-6 and the step keeps the cheap form.
                     if (HAS(HLX_F_OBS_LOS) || RARE(g_det && fabsf(n_g - dpq) < 2e-6f))
-                        dpq = ((HOT(c.g_base_q) * (1.0f - HLX_DIVF(snorm3(g2m), HOT(c.g_max_range)) * 0.4f)) * HOT(c.weather)) * HOT(cur.g_rel);
+                        dpq = ((HOT(c.g_base_q) * (1.0f - HLX_DIVF(snorm3(g2m), HOT(c.g_max_range)) * 0.4f)) * HOT(c.weather)) * cur_g_rel;
                     g_det = g_det && !(n_g > dpq);
                     if (g_det) {
                         {
@@ -1488,6 +1511,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     }
                 }
                 const V3 d_gp = to_v3(d_gp64);
+                if (HLX_ONBOARD_EARLY && HOT(c.o_delay) > 0 && on_have) {      // the delayed onboard sample: first touched here
+                    asm volatile("" : "+v"(on_raw.x), "+v"(on_raw.y), "+v"(on_raw.z), "+v"(on_raw.w));
+                    d_on = v3(on_raw.x, on_raw.y, on_raw.z); d_on_det = on_raw.w > 0.f; on_why = d_on_det ? 0.f : on_raw.w;
+                }
 #ifndef HLX_EARLY_MORE
 #define HLX_EARLY_MORE 0      // A/B: 1 = the ground-ring sample is stored behind the ground-radar section; 2 = the Kalman groups and the packed word behind the filter
 #endif
@@ -1790,7 +1817,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
 #pragma unroll
                 for (int k = 0; k < (HLX_OBS_DIM + 3) / 4; ++k)      // (the two floats behind the 26-float row: the beam test's cosine and threshold)
                     pool_put(PA2, PG_ROW + k, make_float4(row[4 * k], row[4 * k + 1], 4 * k + 2 < HLX_OBS_DIM ? row[4 * k + 2] : beam_cb,
-                                                         4 * k + 3 < HLX_OBS_DIM ? row[4 * k + 3] : HOT(cur.cos_half_beam)));
+                                                         4 * k + 3 < HLX_OBS_DIM ? row[4 * k + 3] : cur_cos_half_beam));
                 G(pp2.tag)[i] = pool_epn;
             }
             const uint32_t blk_bytes = (uint32_t)min(64, n - (int)blockIdx.x * 64) * 16u;   // partial tail block: clip
@@ -1846,7 +1873,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             // (rows of finished lanes hold the first observation of their new episode, exactly the frame the pipeline stacks),
             // and of the discounted returns (VecNormalize._update_reward: returns = returns * gamma + reward).  Fixed summation
             // order, no atomics: the pipeline's finalize kernel adds the blocks' partials in block order.
-            double* const out = HOT(opt.pipe_partial) + (size_t)blockIdx.x * (size_t)HOT(opt.pipe_stride);
+            // (layout [55][blocks], i.e. one contiguous run of `blocks` doubles per quantity: the finalize kernel reads each of them
+            // with coalesced 8-byte loads -- rows of 2 F + 4 doubles per block, as until round 3, made every one of its loads a
+            // cache line of its own)
+            double* const out = HOT(opt.pipe_partial) + (size_t)blockIdx.x;
+            const size_t PB = (size_t)HOT(opt.pipe_stride);        // = number of 64-environment blocks of this launch
             const int c = lane & 31, half = lane >> 5;                  // lanes 0-25: rows 0-31 of column c; lanes 32-57: rows 32-63
             double cs = 0., cq = 0.;
             if (c < HLX_OBS_DIM) {
@@ -1859,8 +1890,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             }
             cs += __shfl_down(cs, 32); cq += __shfl_down(cq, 32);
             if (lane < HLX_OBS_DIM) {
-                G(out)[2 * (HOT(opt.pipe_col0) + lane)] = cs;
-                G(out)[2 * (HOT(opt.pipe_col0) + lane) + 1] = cq;
+                G(out)[(size_t)(2 * lane) * PB] = cs;
+                G(out)[(size_t)(2 * lane + 1) * PB] = cq;
             }
             double rs = 0., rq = 0.;
             if (HOT(opt.pipe_returns)) {
@@ -1874,8 +1905,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             }
             const unsigned long long fin = __ballot(live && done);        // who finished: the finalize kernel subtracts their older frames
             if (lane == 0) {
-                G(out)[HOT(opt.pipe_stride) - 4] = rs; G(out)[HOT(opt.pipe_stride) - 3] = rq;
-                G(out)[HOT(opt.pipe_stride) - 2] = __longlong_as_double((long long)fin);
+                G(out)[(size_t)(2 * HLX_OBS_DIM) * PB] = rs; G(out)[(size_t)(2 * HLX_OBS_DIM + 1) * PB] = rq;
+                G(out)[(size_t)(2 * HLX_OBS_DIM + 2) * PB] = __longlong_as_double((long long)fin);
             }
         }
         if (MODE == 0) {

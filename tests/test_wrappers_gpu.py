@@ -147,7 +147,7 @@ def test_sb3_numpy_contract_of_the_wrapped_env():
     env.close()
 
 
-@pytest.mark.parametrize("n,n_stack", [(4099, 4), (300, 2), (70, 8)])
+@pytest.mark.parametrize("n,n_stack", [(4099, 4), (300, 2), (70, 8), (9000, 4)])
 def test_incremental_moments_equal_the_full_reduction(n, n_stack):
     """Step pushes that follow a training push reduce only the newest frame and subtract the frames of the environments
     that were reset (hlx_obs_moments_inc_kernel); HLX_OBS_FULL_MOMENTS=1 forces the full reduction over all n_stack frames.
@@ -216,3 +216,4 @@ def test_a_file_sb3_itself_wrote_loads_into_the_device_pipeline_or_is_refused_by
               "norm_obs", "norm_reward", "training"):
         assert np.array_equal(back[k], wide[k]), k
     v.close()
+
