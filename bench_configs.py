@@ -220,40 +220,67 @@ def config5(args, rank, local_rank, world, dist):
     base = HlynrVecEnv(scenario_config("medium", "config", {"volley_mode": True, "volley_size": 3}), num_envs=n, device=local_rank,
                        seed=1000, env_id_offset=offset)
     env = VecFrameStack(base, 4)
-    ctl = HRLController(n, obs_dim=104, device=local_rank, decision_interval=100, selector="rules")
+    # a MIXED option population (round-3 review: the rules selector had every environment of the measured run in one option, so
+    # the grouping path was barely exercised): an external selector with seeded choices, decided every 25 steps per environment,
+    # on top of the forced transitions the observations trigger
+    sel_gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    ctl = HRLController(n, obs_dim=104, device=local_rank, decision_interval=25,
+                        selector=lambda a: torch.randint(0, 3, (a.shape[0],), generator=sel_gen, device=a.device, dtype=torch.int32))
     torch.manual_seed(99)
+
+    class LstmCell(torch.nn.Module):
+        """One LSTM layer advanced by one time step, its state updated IN PLACE (the state tensors are views of the controller's
+        resident banks: nothing is copied back).  Same arithmetic as torch.nn.LSTM on a length-1 sequence."""
+
+        def __init__(self, n_in, hidden):
+            super().__init__()
+            self.ih, self.hh = torch.nn.Linear(n_in, 4 * hidden), torch.nn.Linear(hidden, 4 * hidden)
+
+        def forward(self, x, h, c):
+            i, f, g, o = (self.ih(x) + self.hh(h)).chunk(4, dim=1)
+            c.mul_(torch.sigmoid(f)).addcmul_(torch.sigmoid(i), torch.tanh(g))
+            torch.mul(torch.sigmoid(o), torch.tanh(c), out=h)
+            return h
 
     class Specialist(torch.nn.Module):
         """RecurrentPPO-shaped specialist (train_hrl_pretrain.py:421-425): separate 256-unit actor and critic LSTMs."""
 
         def __init__(self):
             super().__init__()
-            self.actor, self.critic = torch.nn.LSTM(104, 256), torch.nn.LSTM(104, 256)
+            self.actor, self.critic = LstmCell(104, 256), LstmCell(104, 256)
             self.pi = torch.nn.Linear(256, 6)
 
         def forward(self, rows, state, starts):
             k = rows.shape[0]
-            if state is None:
+            if state is None:            # very first call: the controller learns the state's shape from what comes back
                 state = tuple(torch.zeros((1, k, 256), device=rows.device) for _ in range(4))
+                fresh = state
+            else:
+                fresh = None
             keep = (~starts).to(rows.dtype).view(1, k, 1)           # episode_start: begin from zeros
-            ha, ca, hc, cc = (s * keep for s in state)
-            out, (ha, ca) = self.actor(rows.unsqueeze(0), (ha.contiguous(), ca.contiguous()))
-            _, (hc, cc) = self.critic(rows.unsqueeze(0), (hc.contiguous(), cc.contiguous()))
-            return torch.tanh(self.pi(out[0])), (ha, ca, hc, cc)
+            for s_ in state:
+                s_.mul_(keep)
+            ha, ca, hc, cc = (s_[0] for s_ in state)                # [k, 256] views of the resident banks
+            out = self.actor(rows, ha, ca)
+            self.critic(rows, hc, cc)
+            return torch.tanh(self.pi(out)), fresh                  # state updated in place: nothing to write back
 
     spec = {k: Specialist().to(dev) for k in (SEARCH, TRACK, TERMINAL)}
     sections = Sections(torch)
     obs = env.reset_torch()
     term = trunc = None
+    names = {"controller": "controller_us", "grouping": "grouping_us", "gather / scatter": "lstm_state_gather_scatter_us",
+             "specialist forward": "specialist_forward_us"}
 
     def loop(T, sec):
         nonlocal obs, term, trunc
+        ctl.section = lambda name: sec(names[name])
         with torch.no_grad():
             for _ in range(T):
-                with sec("controller + specialists (LSTM state gather / forward / scatter)"):
-                    actions, option, info = ctl.select_actions_recurrent(obs, spec, term, trunc)
-                with sec("env step (volley K=3) + frame stack"):
+                actions, option, info = ctl.select_actions_recurrent(obs, spec, term, trunc)
+                with sec("env_step_frame_stack_us"):
                     obs, rew, term, trunc, _ = env.step_torch(actions)
+        ctl.section = None
 
     loop(20, Sections(torch))
     if dist is not None:
@@ -273,10 +300,14 @@ def config5(args, rank, local_rank, world, dist):
         "value": n * world * T / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": T, "warmup": 20,
         "ms_per_step": 1e3 * elapsed / T, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"medium scenario, volley K=3, config.yaml physics, {n} envs/GPU, VecFrameStack(4), HRLController (rules "
-                               f"selector, decision interval 100), three recurrent specialists (actor + critic LSTM 104->256, torch, random weights)",
+        "config": {"workload": f"medium scenario, volley K=3, config.yaml physics, {n} envs/GPU, VecFrameStack(4), HRLController (external "
+                               f"selector with seeded choices, decision interval 25, forced transitions on), three recurrent specialists (actor + "
+                               f"critic LSTM cell 104->256 as torch ops updating the resident state in place, random weights)",
                    "kernel_variant": base.kernel_variant},
         "shares_us_per_step": {k: v / T for k, v in tot.items()},
+        "everything_but_the_specialists_forward_us": sum(v for k, v in tot.items() if k not in ("specialist_forward_us", "env_step_frame_stack_us")) / T,
+        "rows_moved_last_step": ctl.rows_moved,
+        "unattributed_us_per_step": 1e6 * elapsed / T - sum(tot.values()) / T,      # host waits (the one per step for the run lengths) and launch gaps: GPU idle between sections
         "ranks": {"dist_world_size": dist.get_world_size() if dist is not None else 1, "backend": args.backend if dist is not None else None,
                   "per_rank_ms": per_rank_ms},
         "lstm_state_resident_bytes": state_bytes, "lstm_state_bytes_per_env": state_bytes // max(1, n),

@@ -146,6 +146,14 @@ SYMBOLS = {
     "hlx_hrl_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hlx_hrl_get_state": (C.c_int, [_P, _P]),
     "hlx_hrl_set_state": (C.c_int, [_P, _P]),
+    "hlx_hrl_regroup": (C.c_int, [_P, _P, C.POINTER(_P), C.POINTER(i64), i32, _P, i64, _P]),
+    "hlx_hrl_regroup_scratch_bytes": (i64, [i32, C.POINTER(i64), i32]),
+    "hlx_hrl_rows": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "hlx_hrl_unrows": (C.c_int, [_P, _P, i32, _P, _P]),
+    "hlx_hrl_group_counts": (C.c_int, [_P, C.POINTER(i32 * 4)]),
+    "hlx_hrl_order": (_P, [_P]),
+    "hlx_hrl_pos": (_P, [_P]),
+    "hlx_hrl_bind_order": (C.c_int, [_P, _P, _P]),
 }
 
 _lib = None

@@ -9,6 +9,7 @@ option is that specialist's (the reference runs one environment and one speciali
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import Callable, Dict, Optional
 
@@ -57,8 +58,15 @@ class HRLController:
         self.info = torch.zeros(n, dtype=torch.uint8, device=dev)
         self._closed = False
         # recurrent specialists (select_actions_recurrent): one live LSTM state per environment, resident on the device
-        self._fresh = torch.ones(n, dtype=torch.bool, device=dev)    # controller (re)started: the next predict begins an episode
-        self.lstm_state = None                                       # tuple of [layers, N, hidden] tensors, made on first use
+        self.lstm_state = None                                       # tuple of [layers, N, hidden] tensors in OPTION-MAJOR row order, made on first use
+        # option-major row order (include/hlx_hrl.h hlx_hrl_regroup): order[row] = environment, pos[environment] = row -- torch
+        # tensors the library maintains in place (hlx_hrl_bind_order)
+        self.order = torch.arange(n, dtype=torch.int32, device=dev)
+        self.pos = torch.arange(n, dtype=torch.int32, device=dev)
+        _lib.check(self._lib.hlx_hrl_bind_order(self._h, self.order.data_ptr(), self.pos.data_ptr()))
+        self._scratch, self._bank_args, self.rows_moved = None, None, 0
+        self._rows = None            # row-order buffers of select_actions_recurrent: observations, start flags, actions (+ actions in environment order)
+        self.section = None          # optional: callable name -> context manager, entered around each phase of select_actions_recurrent
 
     def _stream(self):
         return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
@@ -82,11 +90,7 @@ class HRLController:
         if mask is not None:
             mask = mask.to(device=self.device, dtype=self._torch.uint8).contiguous()
             m = mask.data_ptr()
-        _lib.check(self._lib.hlx_hrl_reset(self._h, m, self._stream()))
-        if mask is None:
-            self._fresh.fill_(True)
-        else:
-            self._fresh |= mask.bool()
+        _lib.check(self._lib.hlx_hrl_reset(self._h, m, self._stream()))     # (the next decision of these environments carries info bit 7)
 
     def abstract_observation(self, obs):
         """[N, 26k] observation tensor -> [N, 7] abstract state (no controller state is touched)."""
@@ -145,33 +149,92 @@ class HRLController:
                                  action_dim: int = 6):
         """`select_actions` for recurrent specialists (RecurrentPPO, hrl/specialist_policies.py:95-183).
 
-        `specialists[k](obs_rows, state_rows, episode_start_rows) -> (action_rows, new_state_rows)` with `state_rows` a
+        `specialists[k](obs_rows, state_rows, episode_start_rows) -> (action_rows, new_state_rows | None)` with `state_rows` a
         tuple of [layers, rows, hidden] tensors -- the batched form of `model.predict(obs, state=..., episode_start=...)`.
+        `state_rows` are VIEWS of the resident banks: a specialist may update them in place and return `None` for the state
+        (no write-back traffic at all), or return new tensors, which are copied into the views.
 
         The reference keeps an LSTM state per specialist and environment, but resets a specialist's state whenever its
         option is switched away from (manager.py:210-215) and all of them when the episode restarts (manager.py:104-107),
         so at any time an environment has exactly ONE live state: that of its active specialist, begun afresh
         (`episode_start=True`, i.e. zeros) on the step an option is entered or the controller restarted.  That state lives
-        here, on the device, as `self.lstm_state`; per step each specialist sees the rows of its own environments only."""
+        here, on the device, as `self.lstm_state` -- in OPTION-MAJOR row order (round 4; include/hlx_hrl.h hlx_hrl_regroup):
+        `self.order[row]` is the environment of a row, every option's environments are one contiguous run of rows, and a
+        specialist's state is a slice of each bank.  The returned `actions` tensor is reused by the next call.  After the controller has decided, only the rows of environments that
+        changed option (and the few they displace) move -- a few hundred KB per step where gathering and scattering
+        environment-major banks moved 0.5 GB at 65 536 environments.  One host wait per step reads the three run lengths (the
+        slices' bounds); everything else is enqueued without synchronising."""
         t = self._torch
-        option, abstract, info = self.step(obs, terminated, truncated)
-        starts = (info & 1).bool() | self._fresh
-        for flag in (terminated, truncated):            # controllers restarted by hlx_hrl_step before deciding
-            if flag is not None:
-                starts |= flag.to(self.device).bool()
-        self._fresh.zero_()
-        actions = t.zeros((self.num_envs, action_dim), dtype=t.float32, device=self.device)
-        for k, idx in self._rows_by_option(option, specialists):
-            fn = specialists[k]
-            rows = None if self.lstm_state is None else tuple(x.index_select(1, idx) for x in self.lstm_state)
-            act, new = fn(obs.index_select(0, idx), rows, starts.index_select(0, idx))
-            actions.index_copy_(0, idx, act.to(t.float32))
-            if self.lstm_state is None:                 # shapes come from the first specialist that answers
-                self.lstm_state = tuple(t.zeros((x.shape[0], self.num_envs, x.shape[2]), dtype=x.dtype, device=self.device)
-                                        for x in new)
-            for bank, x in zip(self.lstm_state, new):
-                bank.index_copy_(1, idx, x)
+        sec = self.section or (lambda name: contextlib.nullcontext())      # optional per-phase timers (bench_configs.py config5)
+        obs = self._check_obs(obs)
+        with sec("controller"):
+            option, abstract, info = self.step(obs, terminated, truncated)
+        with sec("grouping"):
+            counts = self._regroup(option)
+        with sec("gather / scatter"):
+            # the observation rows and the "state starts afresh" flags (option switched | first decision since the controller
+            # restarted: info bits 0 and 7) in row order -- one launch (hlx_hrl_rows)
+            if self._rows is None or self._rows[2].shape[1] != action_dim:
+                n, dev = self.num_envs, self.device
+                self._rows = (t.empty((n, self.obs_dim), dtype=t.float32, device=dev), t.zeros(n, dtype=t.uint8, device=dev),
+                              t.zeros((n, action_dim), dtype=t.float32, device=dev), t.zeros((n, action_dim), dtype=t.float32, device=dev))
+            obs_rows_all, starts_u8, act_rows, actions = self._rows
+            _lib.check(self._lib.hlx_hrl_rows(self._h, obs.data_ptr(), info.data_ptr(), obs_rows_all.data_ptr(), starts_u8.data_ptr(), self._stream()))
+            starts_rows_all = starts_u8.view(t.bool)
+            if any(counts[k] and k not in specialists for k in range(3)):
+                act_rows.zero_()                              # an option without a specialist acts with zeros
+        off = 0
+        for k in range(3):
+            c = counts[k]
+            if c and k in specialists:
+                rows = None if self.lstm_state is None else tuple(x[:, off:off + c] for x in self.lstm_state)
+                with sec("specialist forward"):
+                    act, new = specialists[k](obs_rows_all[off:off + c], rows, starts_rows_all[off:off + c])
+                with sec("gather / scatter"):
+                    act_rows[off:off + c] = act.to(t.float32)
+                    if new is not None:
+                        if self.lstm_state is None:         # shapes come from the first specialist that answers
+                            self.lstm_state = tuple(t.zeros((x.shape[0], self.num_envs, x.shape[2]), dtype=x.dtype, device=self.device) for x in new)
+                            rows = tuple(x[:, off:off + c] for x in self.lstm_state)
+                        for dst, x in zip(rows, new):
+                            dst.copy_(x)
+            off += c
+        with sec("gather / scatter"):      # ... and the actions back into environment order: one launch (hlx_hrl_unrows)
+            _lib.check(self._lib.hlx_hrl_unrows(self._h, act_rows.data_ptr(), action_dim, actions.data_ptr(), self._stream()))
         return actions, option, info
+
+    def _regroup(self, option):
+        """hlx_hrl_regroup + the one host wait of the step: the three run lengths.  Rows of the resident banks move inside them."""
+        t = self._torch
+        if self.lstm_state is not None:
+            key = tuple(x.data_ptr() for x in self.lstm_state)
+            if self._bank_args is None or self._bank_args[0] != key:      # the ctypes arguments are built once per set of banks, not per step
+                banks = []
+                for x in self.lstm_state:
+                    if not x.is_contiguous() or x.device != self.device or x.shape[1] != self.num_envs:
+                        raise ValueError("resident state banks must be contiguous [layers, N, hidden] tensors on the controller's device")
+                    banks += [x[layer] for layer in range(x.shape[0])]      # [N, hidden] each, contiguous
+                nb = len(banks)
+                rb = (C.c_int64 * nb)(*[b.shape[1] * b.element_size() for b in banks])
+                need = int(self._lib.hlx_hrl_regroup_scratch_bytes(self.num_envs, rb, nb))
+                if self._scratch is None or self._scratch.numel() < need:
+                    self._scratch = t.empty(need, dtype=t.uint8, device=self.device)
+                arr = (C.c_void_p * nb)(*[b.data_ptr() for b in banks])
+                self._bank_args = (key, arr, rb, nb, self._scratch.data_ptr(), self._scratch.numel())
+            _, arr, rb, nb, sp, sn = self._bank_args
+            _lib.check(self._lib.hlx_hrl_regroup(self._h, option.data_ptr(), arr, rb, nb, sp, sn, self._stream()))
+        else:
+            _lib.check(self._lib.hlx_hrl_regroup(self._h, option.data_ptr(), None, None, 0, None, 0, self._stream()))
+        out = (C.c_int32 * 4)()
+        _lib.check(self._lib.hlx_hrl_group_counts(self._h, C.byref(out)))
+        self.rows_moved = int(out[3])
+        return [int(out[0]), int(out[1]), int(out[2])]
+
+    def lstm_state_of(self, env_indices):
+        """The resident state rows of the given environments (copies; diagnostics and tests): tuple of [layers, len, hidden]."""
+        t = self._torch
+        rows = self.pos.to(t.int64).index_select(0, t.as_tensor(env_indices, device=self.device, dtype=t.int64))
+        return tuple(x.index_select(1, rows) for x in self.lstm_state)
 
     @staticmethod
     def decode_info(info_byte: int) -> Dict[str, object]:

@@ -33,7 +33,9 @@ typedef struct hlx_hrl hlx_hrl;
 enum { HLX_OPT_SEARCH = 0, HLX_OPT_TRACK = 1, HLX_OPT_TERMINAL = 2 };            /* option_definitions.py:10-14 */
 enum { HLX_SEL_FIXED = 0, HLX_SEL_RULES = 1, HLX_SEL_EXTERNAL = 2 };             /* selector_policy.py modes */
 /* hlx_hrl_step info byte: bit0 option switched, bits1-2 switch reason (0 continue, 1 selector, 2 forced),
- * bit3 a forced transition fired, bit4 the selector was due this step, bits5-6 'hrl/selector_choice' */
+ * bit3 a forced transition fired, bit4 the selector was due this step, bits5-6 'hrl/selector_choice',
+ * bit7 this is the first decision since the controller (re)started (hlx_hrl_reset, or a done flag of the previous step): with
+ * bit0, the steps on which a recurrent specialist's state starts afresh (manager.py:104-107, 210-215) */
 
 typedef struct hlx_hrl_config {
     int32_t n_envs;
@@ -75,6 +77,47 @@ int hlx_hrl_step(hlx_hrl *h, const float *obs, const uint8_t *done_a, const uint
  * total_steps.  Synchronises. */
 int hlx_hrl_get_state(hlx_hrl *h, int32_t *host_out);
 int hlx_hrl_set_state(hlx_hrl *h, const int32_t *host_in);
+
+/* ---- Option-major residency of per-environment recurrent state (round 4) ---------------------------------------------------
+ * The specialists are recurrent (RecurrentPPO: hrl/specialist_policies.py:95-183; separate 256-unit actor / critic LSTMs,
+ * train_hrl_pretrain.py:421-425 -> 4 KiB of hidden state per environment) and each one runs on the environments whose ACTIVE
+ * option is its own (manager.py:109-215).  Gathering those rows out of environment-major state banks and scattering them back is
+ * 0.5 GB of traffic per step at 65 536 environments.  Instead the controller keeps a ROW ORDER in which every option's
+ * environments are one contiguous run -- order[row] = environment, pos[environment] = row -- so that a specialist's state is a
+ * slice of each bank, and hlx_hrl_regroup restores that property after the options have moved by relocating ONLY the rows that
+ * have to move: an environment that switches option takes a row of its new run (its state restarts there anyway:
+ * manager.py:210-215), and the row it leaves is filled from the end of its old run.  A few hundred 1-KiB rows per step instead of
+ * 65 536 x 4 KiB twice.
+ *
+ * hlx_hrl_regroup(h, option, banks, row_bytes, n_banks, scratch, scratch_bytes, stream)
+ *   option    [N] device: the active option of every environment after hlx_hrl_step (its option_out).
+ *   banks     HOST array of n_banks (<= 8) DEVICE pointers, bank b a [N][row_bytes[b]] array in ROW order (row r belongs to
+ *             environment order[r]); rows are moved inside them.  n_banks may be 0 (only order / pos are maintained).
+ *   row_bytes HOST array: the row size of every bank, a positive multiple of 4 (multiples of 16 move in 16-byte units).
+ *   scratch   device, 16-byte aligned, at least hlx_hrl_regroup_scratch_bytes(N, row_bytes, n_banks) bytes (staging for the rows
+ *             that move; checked against scratch_bytes); may be NULL when n_banks == 0.
+ *   Enqueues four small launches (count, classify, gather, scatter; the run lengths reach the host through pinned memory, written
+ *   by the classify launch's last block); nothing synchronises.  Afterwards rows [0, c0) hold the
+ *   environments whose option is 0, [c0, c0 + c1) option 1, the rest option 2.  WHICH row inside its run an environment gets is
+ *   not defined (rows are claimed with atomics); everything a caller computes per environment is independent of it.
+ * hlx_hrl_group_counts(h, out) waits for the latest regroup on the HOST (one event) and returns {c0, c1, c2, rows moved}.
+ * hlx_hrl_order / hlx_hrl_pos: the two DEVICE int32[N] maps (valid after the latest regroup in stream order).
+ * hlx_hrl_bind_order(h, order, pos): keep the two maps in CALLER-owned device arrays (e.g. torch tensors, which the caller indexes
+ *   with) instead of the library's own; NULL, NULL returns to those.  The order restarts from the identity (synchronises).
+ * hlx_hrl_reset leaves the order alone: the next regroup sees the reset environments' new options like any other switch. */
+int hlx_hrl_regroup(hlx_hrl *h, const uint8_t *option, void *const *banks, const int64_t *row_bytes, int32_t n_banks, void *scratch,
+                    int64_t scratch_bytes, void *stream);
+int64_t hlx_hrl_regroup_scratch_bytes(int32_t n_envs, const int64_t *row_bytes, int32_t n_banks);
+/* Around the specialists' forward passes, in the row order of the latest regroup (device pointers, nothing synchronises):
+ * hlx_hrl_rows: obs_rows[r][:] = obs[order[r]][:] ([N][obs_dim]) and starts_rows[r] = 1 where environment order[r]'s recurrent
+ *   state starts afresh on this step (info bits 0 and 7 of hlx_hrl_step), else 0 (uint8; may be NULL);
+ * hlx_hrl_unrows: actions[order[r]][:] = act_rows[r][:] ([N][act_dim]). */
+int hlx_hrl_rows(hlx_hrl *h, const float *obs, const uint8_t *info, float *obs_rows, uint8_t *starts_rows, void *stream);
+int hlx_hrl_unrows(hlx_hrl *h, const float *act_rows, int32_t act_dim, float *actions, void *stream);
+int hlx_hrl_group_counts(hlx_hrl *h, int32_t out[4]);
+const int32_t *hlx_hrl_order(const hlx_hrl *h);
+const int32_t *hlx_hrl_pos(const hlx_hrl *h);
+int hlx_hrl_bind_order(hlx_hrl *h, int32_t *order, int32_t *pos);
 
 #ifdef __cplusplus
 }

@@ -143,6 +143,10 @@ def test_bench_config5_volley_hrl_lstm_small():
     assert d["n_gpus"] == 1 and d["steps"] == 20 and "configs[4]" in d["metric"]
     assert all(_finite(v) and v > 0 for v in d["shares_us_per_step"].values())
     assert d["lstm_state_bytes_per_env"] == 4096 and sum(d["options_now"]) == 4096
+    # round 4: this repository's share of the controller step is reported apart from the caller's networks, and the measured
+    # run has a MIXED option population (every specialist serves some environments)
+    assert set(d["shares_us_per_step"]) >= {"controller_us", "grouping_us", "lstm_state_gather_scatter_us", "specialist_forward_us"}
+    assert min(d["options_now"]) > 0 and _finite(d["everything_but_the_specialists_forward_us"])
 
 
 @pytest.mark.gpu

@@ -62,6 +62,9 @@ def test_argument_validation_without_a_device():
     assert hc.h_lock_acquire == 0.75 and list(hc.min_dwell) == [50, 50, 30] and hc.close_range == 200.0
     assert lib.hlx_hrl_create(C.byref(hc), C.byref(p)) == -1 and b"obs_dim" in lib.hlx_last_error()
     assert lib.hlx_hrl_step(None, None, None, None, None, None, None, None, None) == -1 and lib.hlx_hrl_destroy(None) == 0
+    assert lib.hlx_hrl_regroup(None, None, None, None, 0, None, 0, None) == -1 and lib.hlx_hrl_rows(None, None, None, None, None, None) == -1
+    rb = (C.c_int64 * 2)(1024, 20)           # staging area of hlx_hrl_regroup: every bank's N rows, each region rounded up to 16 bytes
+    assert lib.hlx_hrl_regroup_scratch_bytes(100, rb, 2) == 102400 + 2000 and lib.hlx_hrl_regroup_scratch_bytes(3, rb, 2) == 3072 + 64
 
 
 def test_config_struct_carries_the_flags():
