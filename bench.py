@@ -250,7 +250,11 @@ def measured_traffic(physics, n, form="single_pass"):
     try:
         with open(path) as f:
             table = json.load(f)
-            d = table.get(f"{physics}:{n}:{form}") or table.get(f"{physics}:{n}", {})      # per form where measured (round 3: contract)
+            d = table.get(f"{physics}:{n}:{form}")      # this workload in this form, or nothing: a figure is never borrowed from another configuration
+            if d is None and form == "single_pass":
+                d = table.get(f"{physics}:{n}")          # (the entries without a form are round-1/2 measurements of the single-pass launch)
+            if d is None:
+                return None, None
             return d.get("hbm_bytes_per_launch"), "static: profiles/hbm_traffic.json (%s)" % d.get("source", "rocprofv3 --pmc, committed")
     except OSError:
         return None, None

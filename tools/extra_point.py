@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 def main():
     import torch
 
-    from bench import BYTES_PER_ENV_STEP, FORM_BYTES_DELTA, HBM_PEAK_GBS, tape_schedule
+    from bench import BYTES_PER_ENV_STEP, FORM_BYTES_DELTA, HBM_PEAK_GBS, measured_traffic, tape_schedule
     from hlynr_intercept_amd.config import resolve_config
     from hlynr_intercept_amd.scenarios import scenario_config
     from hlynr_intercept_amd.vec_env import HlynrVecEnv
@@ -45,7 +45,8 @@ def main():
         out.append({"workload": f"medium scenario, {phys} physics, {n} envs/GPU", "form": form, "value": n * k / dt, "unit": "env-steps/s",
                     "us_per_step": 1e6 * dt / k, "algorithmic_bytes_per_env_step": b, "form_bytes_per_env_step": bf, "desync_steps": d,
                     "steps": k, "process": "fresh", "roofline_frac": n * k * b / dt / 1e9 / HBM_PEAK_GBS,
-                    "roofline_frac_form_bytes": n * k * bf / dt / 1e9 / HBM_PEAK_GBS})
+                    "roofline_frac_form_bytes": n * k * bf / dt / 1e9 / HBM_PEAK_GBS,
+                    "traffic": measured_traffic(phys, n, form)[0]})      # HBM bytes per launch by counters for THIS workload and form (profiles/hbm_traffic.json), or None
     env.close()
     print(json.dumps(out), flush=True)
 
