@@ -503,6 +503,7 @@ def main():
                  "note": "same K steps through hlx_rollout with hlx_set_rollout_fused: state stays in registers for "
                          "steps_per_launch steps, bit-identical results; not the headline (a policy in the loop needs one launch per step)"}
 
+    pool_info["auto_resets_computed_in_crowded_waves"] = env.episode_pool_crowded()
     pool_info["auto_resets_computed_inside_step_launches"] = env.episode_pool_misses()     # (all forms of this run; the single-pass form and the fused rollout always compute in place)
     # config 3 and a batch whose state (2.6 GB) defeats the 256 MB Infinity Cache -- each in a FRESH process
     # (tools/extra_point.py: at HBM-bound sizes the step's time depends on the process's whole allocation history)

@@ -110,6 +110,7 @@ SYMBOLS = {
     "hlx_set_episode_pool": (C.c_int, [_P, i32]),
     "hlx_get_episode_pool": (i32, [_P]),
     "hlx_get_episode_pool_misses": (C.c_int, [_P, C.POINTER(i64)]),
+    "hlx_get_episode_pool_crowded": (C.c_int, [_P, C.POINTER(i64)]),
     "hlx_get_episode_pool_stats": (C.c_int, [_P, C.POINTER(i64 * 4)]),
     "hlx_set_load_schedule": (C.c_int, [_P, i32]),
     "hlx_get_load_schedule": (i32, [_P]),

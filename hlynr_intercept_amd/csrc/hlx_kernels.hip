@@ -116,7 +116,7 @@ struct PoolPtrs {
     size_t blocks;          // 64-environment blocks
     float4* pool;           // [blocks][POOL_GROUPS][64]
     uint32_t *tag, *ep_cur; // [blocks * 64] each
-    int32_t* rf_cnt;            // [4]: [2] = respawns computed inside step launches (diagnostics)
+    int32_t* rf_cnt;            // [4]: [2] = respawns computed inside step launches for want of an entry, [3] = ... in a crowded wave (diagnostics)
     unsigned long long* rf_mask;   // [blocks]: the lanes of each block that have used their entry since the last fill
 };
 // the pool lives behind the rings in the arena allocation (hlx_host.inc hlx_create computes the same addresses)
@@ -904,9 +904,57 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         // below, so that waiting for it later does not wait for them -- and is unpacked when the observation pass is over
         // (`pf` is deliberately left without an initial value: it is written and read under `hit_pf` only, and a zero on the
         // other path makes the compiler merge the two with copies behind the loads -- i.e. wait for them on the spot)
+#ifndef HLX_COOP_RESPAWN
+#define HLX_COOP_RESPAWN 1
+#endif
+        // Round 4: the WAVE copies a prepared episode, not the lane that finished.  The stamps showed where a launch's tail still came
+        // from (profiles/r04_stamps_contract_base_p99.txt): the slowest 1-5 % of the waves are the ones with a finished lane, and they
+        // spend 3 900 cycles at the loop exit (280 for the others) plus 1 000 in the section that requests the entry -- one lane
+        // executing ~30 16-byte loads, ~90 accumulation-register reads, the unpacking of every state word and the ~25 stores of the
+        // final section on behalf of its new episode, 330 wave instructions for 512 bytes.  An entry is POOL_GROUPS 16-byte words:
+        // lane l of the wave now loads word l of the finished lane's entry (ONE load instruction per finished lane, up to COOP_MAX of
+        // them per wave; a wave with more computes the others in place), keeps it in ONE register quad through the observation pass,
+        // and stores it where that word belongs -- state group l of the finished lane's arena slot, the ring planes, the finished
+        // lane's row of the observation tile -- behind the wave's own final stores.  The finished lane's registers keep the old
+        // episode; its own (stale) stores to those addresses are issued first and overwritten in order.  -DHLX_COOP_RESPAWN=0: the
+        // round-3 form (A/B).
+        constexpr int COOP_MAX = 4;
+        float4 coop[COOP_MAX];                 // (deliberately uninitialised, like `pf`: written and read under `coop_mask` only)
+        const bool coop_whole = n - (int)blockIdx.x * 64 >= 64;      // a whole block: every lane of the wave is at work
+        unsigned long long coop_mask = 0ull;   // the finished lanes of this wave whose prepared episode the wave copies
+        unsigned long long coop_over = 0ull;   // ... and the ones beyond COOP_MAX with a good entry: computed in place, counted apart from misses
+        float2 coop_beam = make_float2(2.f, -2.f);   // a finished lane's OWN copy of the beam test its entry was computed with (cosine, threshold)
         float4 pf[POOL_GROUPS];
         bool hit_pf = false;
-        if (LONE) {
+        if (LONE && HLX_COOP_RESPAWN) {
+            // (whole blocks only: the copy needs lanes 0 .. POOL_GROUPS - 1 at work; the environments of a partial tail block
+            // compute their next episode in place, like any environment whose entry is not there -- same bits)
+            if (RARE(__ballot(done) != 0ull) && (slots & (1u << 24)) != 0u && !single && coop_whole) {
+                unsigned long long m = __ballot(done && pre_tag == pre_ep + 1u);
+                const PoolPtrs pq = pool_ptrs(arena, n, g_planes, o_planes);
+                const float4* const PB = pq.pool + (size_t)blockIdx.x * (POOL_GROUPS * 64);
+#pragma unroll
+                for (int k = 0; k < COOP_MAX; ++k) {
+                    if (m != 0ull) {
+                        const int d = __builtin_ctzll(m);
+                        m &= m - 1ull;
+                        coop_mask |= 1ull << d;
+                        if (lane < POOL_GROUPS) coop[k] = pool_get(PB + d, lane);      // word `lane` of lane d's entry: PB[lane * 64 + d]
+                    }
+                }
+                coop_over = m;
+                hit_pf = ((coop_mask >> lane) & 1ull) != 0ull;
+                // (the finished lane fetches the two floats that decide whether its entry is still valid for itself: a cross-lane
+                // read of the quad above would be a v_readlane of a register the allocator may have parked in an accumulation
+                // register in between -- the hazard hotcheck.py refuses)
+                if (hit_pf) {
+                    typedef float f2v_ __attribute__((ext_vector_type(2)));
+                    const f2v_ bt = *(const __attribute__((address_space(1))) f2v_*)(reinterpret_cast<const float*>(PB + (POOL_GROUPS - 1) * 64 + lane) + 2);
+                    coop_beam = make_float2(bt.x, bt.y);
+                }
+            }
+        }
+        if (LONE && !HLX_COOP_RESPAWN) {
             if (RARE(__ballot(done) != 0ull) && (slots & (1u << 24)) != 0u && !single) {
                 hit_pf = done && pre_tag == pre_ep + 1u;
                 if (hit_pf) {
@@ -1089,7 +1137,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                         // other, and a copy fetched at the end of the pass measured slower than computing -- 16.2 against 15.9 us at
                         // 131 072 environments.  The host sets bit 24 for the lone-wave schedule only.)
                         if (POOL_PRE) hit = LONE ? hit_pf : false;
-                        if (LONE && hit) {
+                        if (LONE && HLX_COOP_RESPAWN) hit = false;      // (decided for the whole wave below: coop_mask)
+                        if (LONE && !HLX_COOP_RESPAWN && hit) {
                             // The one curriculum scalar the reference really ramps (config.yaml:85-92: the beam width, 120 -> 60 degrees over
                             // 3 M steps, moved by EVERY call of set_training_step_count) enters a first observation through one decision:
                             // cosine of the off-boresight angle against the threshold.  The entry carries that cosine and the threshold it
@@ -1106,11 +1155,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     }
                     if (MODE == 2) pool_epn = epn;
                 }
+                if (LONE && HLX_COOP_RESPAWN && coop_mask != 0ull) {
+                    // the beam test each copied entry was computed with, against today's threshold (see the round-3 form below / hlx.h)
+                    const float ctn = cur_cos_half_beam, cbe = coop_beam.x, cte = coop_beam.y;
+                    const bool ok = (cbe - ctn > 1e-5f && cbe - cte > 1e-5f) || (ctn - cbe > 1e-5f && cte - cbe > 1e-5f);
+                    coop_mask &= __ballot(done && hit_pf && ok);
+                    hit = done && ((coop_mask >> lane) & 1ull) != 0ull;
+                }
                 if (MODE == 2) dmask = __ballot(done);
                 const unsigned long long smask = __ballot(done && !hit);     // the lanes that compute their respawn here
                 float rd[RS_ITEMS][4];
+                if (!(LONE && HLX_COOP_RESPAWN) || smask != 0ull) {     // (44 moves the wave of a copied episode has no use for)
 #pragma unroll
-                for (int j = 0; j < RS_ITEMS; ++j) rd[j][0] = rd[j][1] = rd[j][2] = rd[j][3] = 0.f;
+                    for (int j = 0; j < RS_ITEMS; ++j) rd[j][0] = rd[j][1] = rd[j][2] = rd[j][3] = 0.f;
+                }
                 asm volatile("" : "+v"(rsalt));
                 // lanes 0..10, the ones that serve, are live (a pool fill has every lane at work: each draws for itself)
                 const bool wide = MODE != 2 && (n - (int)blockIdx.x * 64) >= RS_ITEMS;
@@ -1169,8 +1227,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     // compute their respawn here (diagnostics: hlx_get_episode_pool_misses)
                     if (lane == __builtin_ctzll(dmask)) {
                         (void)__hip_atomic_fetch_or(G(pp.rf_mask) + blockIdx.x, dmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (smask != 0ull && !single)      // (the single-pass form computes in place by design: not a miss)
-                            (void)__hip_atomic_fetch_add(G(pp.rf_cnt) + 2, __popcll(smask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (smask != 0ull && !single) {    // (the single-pass form computes in place by design: not a miss)
+                            // [2] the entry was absent or stale; [3] it was there, but the wave had more finished lanes than it copies for
+                            // (a batch-wide truncation step: everyone computing at once is the faster way through that one launch)
+                            const unsigned long long over = LONE && HLX_COOP_RESPAWN ? smask & coop_over : 0ull;
+                            if ((smask & ~over) != 0ull)
+                                (void)__hip_atomic_fetch_add(G(pp.rf_cnt) + 2, __popcll(smask & ~over), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (RARE(over != 0ull))
+                                (void)__hip_atomic_fetch_add(G(pp.rf_cnt) + 3, __popcll(over), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+                if (LONE && HLX_COOP_RESPAWN && coop_whole && MODE == 0 && pass == 1 && HOT(opt.terminal_obs)) {
+                    // the terminal observation of every finished lane, copied by the WAVE: lanes 0-12 move one 8-byte pair each of the
+                    // finished lane's row of the tile (pass 0's observation of the terminal state) -- one LDS read and one store per
+                    // finished lane where the lane itself issued thirteen of each
+                    typedef float f2v_ __attribute__((ext_vector_type(2)));
+                    typedef __attribute__((address_space(1))) f2v_ gf2v_;
+                    unsigned long long mm = dmask;
+                    while (mm != 0ull) {
+                        const int d = __builtin_ctzll(mm);
+                        mm &= mm - 1ull;
+                        if (lane < HLX_OBS_DIM / 2) {
+                            const f2v_ tv = reinterpret_cast<const f2v_*>(tile + d * HLX_OBS_DIM)[lane];
+                            ((gf2v_*)(HOT(opt.terminal_obs) + ((size_t)blockIdx.x * 64 + (size_t)d) * HLX_OBS_DIM))[lane] = tv;
+                        }
                     }
                 }
                 if (done) {
@@ -1187,7 +1268,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                         n_gv = d3((double)rd[5][0], (double)rd[5][1], (double)rd[5][2]);
                     }
                     if (MODE == 0 && pass == 1) {
-                        if (HOT(opt.terminal_obs)) {
+                        if (HOT(opt.terminal_obs) && !(LONE && HLX_COOP_RESPAWN && coop_whole)) {
                             // the lane's row of the LDS tile (pass 0's observation of the terminal state) -> terminal_obs[i]: all
                             // thirteen 8-byte LDS reads first, then thirteen GLOBAL stores (through a generic pointer the
                             // compiler must assume the store may hit LDS and serialises read / wait / store 26 times)
@@ -1318,6 +1399,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                     p_pp = 1000.f; p_pv = 0.f; p_vp = 0.f; p_vv = 1000.f;
                     prev_distance = reld; last_distance = reld; min_distance = reld; // :579-589
                     worsening = 0; crossed = false;
+                    } else if (LONE && HLX_COOP_RESPAWN) {
+                        // the wave copies this lane's prepared episode behind the final stores (below): nothing to unpack.  The dword
+                        // plane is the one piece of state an entry does not hold: a new episode has used no fuel
+                        fuel_used = 0.f;
                     } else {
                         // ---------------- the episode was prepared by a pool fill: state groups, ring samples, observation row
                         // (unpacked exactly as at kernel entry; what the fill stored is what the store section below packs)
@@ -1775,7 +1860,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
             // fused rollout: the state stays in the registers it was loaded into; otherwise it goes back to the arena
 #define PUT4(G, reg, ...) do { if (PERSIST) reg = __VA_ARGS__; else STG(G, __VA_ARGS__); } while (0)
 #define PUT2(G, reg, ...) do { if (PERSIST) reg = __VA_ARGS__; else STG(G, __VA_ARGS__); } while (0)
-            if (!EARLY_ST || RARE(done)) {
+            if (!EARLY_ST || RARE(done && !(LONE && HLX_COOP_RESPAWN && ((coop_mask >> lane) & 1ull) != 0ull))) {
             PUT4(G_IPOS, g_ipos, make_float4(ipos.x, ipos.y, ipos.z, fuel));
             PUT4(G_IVEL, g_ivel, make_float4(ivel.x, ivel.y, ivel.z, prev_distance));
             PUT4(G_QUAT, g_quat, make_float4(q.w, q.x, q.y, q.z));
@@ -1834,6 +1919,43 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                      make_float4(__int_as_float(__double2loint(g_sp.z)), __int_as_float(__double2hiint(g_sp.z)), g_sq, g_sflag));
                 wt16(__builtin_amdgcn_make_buffer_rsrc(R + 2 * N, 0, blk_bytes, 0x00020000), lane16, 0u, g_s2);
             }
+        }
+        if (LONE && HLX_COOP_RESPAWN && RARE(coop_mask != 0ull)) {
+            // ---- the wave stores the prepared episodes it holds: word `lane` of each entry goes where the finished lane's own final
+            // stores (just issued, with the OLD episode's values) put that word.  One descriptor over the whole allocation: arena
+            // blocks, ground ring and onboard ring all lie behind `arena` (hlx_host.inc), offsets fit 32 bits at the batch sizes the
+            // lone-wave schedule serves.
+            const __amdgpu_buffer_rsrc_t rsAll = __builtin_amdgcn_make_buffer_rsrc(arena, 0, 0x7FFFFFFF, 0x00020000);
+            const uint32_t blocks = (uint32_t)((n + 63) >> 6);
+            const uint32_t gring_off = blocks * (uint32_t)(N_GROUPS * 1024), oring_off = gring_off + (uint32_t)(g_planes * GROUND_RING_WORDS16) * (uint32_t)n * 16u;
+            const int g = lane;
+            const bool st_word = g <= G_KFP || (g == G_THRUST && (HAS(HLX_F_THRUST_LAG) || HAS(HLX_F_DOMAIN_RAND))) || (g == G_MISC && HAS(HLX_F_DOMAIN_RAND)) ||
+                                 (g >= G_VPOS && g < N_GROUPS && HAS(HLX_F_VOLLEY) && ((g - G_VPOS) % HLX_MAX_VOLLEY) < VK);
+            const bool on_word = g == PG_ON && HOT(c.o_delay) > 0;
+            const bool gr_word = g >= PG_GR && g < PG_ROW && HAS(HLX_F_GROUND) && HOT(c.g_delay) > 0;
+            const bool row_word = g >= PG_ROW && g < POOL_GROUPS;
+            unsigned long long mm = coop_mask;
+#pragma unroll
+            for (int k = 0; k < COOP_MAX; ++k) {
+                if (mm != 0ull) {
+                    const uint32_t d = (uint32_t)__builtin_ctzll(mm);
+                    mm &= mm - 1ull;
+                    const uint32_t e = (uint32_t)blockIdx.x * 64u + d;      // the finished environment
+                    uint32_t off = 0u;
+                    if (st_word) off = (uint32_t)blockIdx.x * (uint32_t)(N_GROUPS * 1024) + (uint32_t)g * 1024u + d * 16u;
+                    if (on_word) off = oring_off + ((uint32_t)o_wslot * (uint32_t)n + e) * 16u;
+                    if (gr_word) off = gring_off + (((uint32_t)g_wslot * GROUND_RING_WORDS16 + (uint32_t)(g - PG_GR)) * (uint32_t)n + e) * 16u;
+                    if (st_word || on_word || gr_word) wt16(rsAll, off, 0u, coop[k]);
+                    if (row_word) {      // the entry's observation row -> the finished lane's row of the tile (26 floats: the last word holds two)
+                        float* r = tile + d * HLX_OBS_DIM + 4 * (g - PG_ROW);
+                        r[0] = coop[k].x; r[1] = coop[k].y;
+                        if (4 * (g - PG_ROW) + 2 < HLX_OBS_DIM) { r[2] = coop[k].z; r[3] = coop[k].w; }
+                    }
+                }
+            }
+            // the one piece of state an entry does not hold: a new episode has used no fuel (the lane's own final stores, which
+            // would have carried it, are skipped for a copied episode)
+            if (((coop_mask >> lane) & 1ull) != 0ull) STAUX(0.f);
         }
         if (MODE == 0) {
             if (RARE((slots & (1u << 20)) && !(slots & (1u << 23))) && HOT(opt.info.flags))

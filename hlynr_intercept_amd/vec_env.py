@@ -498,9 +498,17 @@ class HlynrVecEnv(_SB3VecEnv):
         return int(self._lib.hlx_get_episode_pool(self._h))
 
     def episode_pool_misses(self) -> int:
-        """Auto-resets that were computed inside a step launch although the pool was on (diagnostics; synchronises)."""
+        """Auto-resets that were computed inside a step launch, pool on, because their prepared episode was absent or stale
+        (diagnostics; synchronises)."""
         out = C.c_int64(0)
         _lib.check(self._lib.hlx_get_episode_pool_misses(self._h, C.byref(out)))
+        return int(out.value)
+
+    def episode_pool_crowded(self) -> int:
+        """... and the ones computed there although it was ready: a wave copies the prepared episodes of up to four finished
+        environments per launch; in a wave with more (a batch-wide max_steps truncation) the rest compute in place (hlx.h)."""
+        out = C.c_int64(0)
+        _lib.check(self._lib.hlx_get_episode_pool_crowded(self._h, C.byref(out)))
         return int(out.value)
 
     def episode_pool_stats(self) -> Dict[str, int]:

@@ -313,10 +313,16 @@ int hlx_profile_read(hlx_env *env, double *total_ms, int64_t *launches);
  * -1 = the default (128).  hlx_get_episode_pool returns the interval in force (0 = off).  Prepared episodes are used by the
  * lone-wave load schedule only (hlx_set_load_schedule 2: batches of at most one wave per SIMD, where the stragglers of a launch
  * are exposed); under the other schedules every auto-reset is computed in place, from the same draws, and no fill is launched.
- * hlx_get_episode_pool_misses: auto-resets computed inside step launches so far, pool on (synchronises; diagnostics). */
+ * hlx_get_episode_pool_misses: auto-resets computed inside step launches so far because the prepared episode was absent or stale,
+ *   pool on (synchronises; diagnostics).
+ * hlx_get_episode_pool_crowded: ... and the ones computed there although it was ready.  Under the lone-wave schedule a WAVE copies the
+ *   prepared episodes of its finished environments, up to four per step launch; the others of a wave with more -- in practice the one
+ *   launch in which a whole batch started together runs into max_steps together -- compute theirs in place, all at once, which is
+ *   the faster way through that launch (same bits either way). */
 int hlx_set_episode_pool(hlx_env *env, int32_t interval);
 int32_t hlx_get_episode_pool(const hlx_env *env);
 int hlx_get_episode_pool_misses(hlx_env *env, int64_t *misses);
+int hlx_get_episode_pool_crowded(hlx_env *env, int64_t *crowded);
 /* The pool under a moving curriculum (environment.py:274-351; the reference's trainers call set_training_step_count after EVERY
  * step, train_flat_ppo.py:171-177).  A first observation reads three curriculum scalars.  The radar BEAM WIDTH -- the one the
  * shipped curriculum ramps (config.yaml:85-92) -- costs nothing: every prepared episode remembers the beam test it was computed

@@ -671,6 +671,11 @@ def test_next_episode_pool_changes_when_work_is_done_never_a_result(physics, ove
     m_every, m_eight, m_long = (e.episode_pool_misses() for e in envs[1:])
     assert envs[0].episode_pool_misses() == 0                 # (pool off: nothing is counted)
     assert m_every < 0.02 * done_total, (m_every, done_total)
+    # (max_steps = 19 here: most episodes of this batch end TOGETHER, by truncation -- waves with more finished environments than
+    # a wave copies prepared episodes for (four); the rest of such a wave compute theirs in place and are counted apart)
+    crowded = envs[1].episode_pool_crowded()
+    assert 0 < crowded and crowded + m_every <= done_total, (crowded, m_every, done_total)
+    assert envs[0].episode_pool_crowded() == 0
     assert m_every <= m_eight <= m_long and m_long > 0.3 * done_total, (m_every, m_eight, m_long, done_total)
     # single-pass form and fused rollout against the contract form, pool on
     a, b, c = (_env(n, physics=physics, over=over, seed=5) for _ in range(3))

@@ -23,6 +23,7 @@ for form in ${FORMS:-contract single_pass}; do
   find $OUT/stats_$form -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats_$form.csv \;
   head -4 $OUT/kernel_stats_$form.csv
 done
+if [ -n "$SKIP_PMC" ]; then exit 0; fi      # SKIP_PMC=1: no counter passes
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_VALU_TRANS" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM" \
