@@ -91,6 +91,7 @@ SYMBOLS = {
     "hlx_create": (C.c_int, [C.POINTER(HlxConfig), i32, i32, u64, i64, C.POINTER(_P)]),
     "hlx_destroy": (C.c_int, [_P]),
     "hlx_reset": (C.c_int, [_P, _P, _P, _P]),
+    "hlx_reset_info": (C.c_int, [_P, _P, _P, _P, _P]),
     "hlx_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(HlxInfoSoa), _P]),
     "hlx_rollout": (C.c_int, [_P, _P, i32, i32, _P, _P, _P, _P, _P]),
     "hlx_set_global_step": (C.c_int, [_P, i64]),

@@ -1626,10 +1626,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
                 const float agree = 1.0f - fminf(fnorm_out(d_on - d_gp) * 0.005f, 1.0f);
                 const float f_both = clampf((float)(0.35 * HOT(c.radar_quality64)) + 0.50f * d_gq + 0.15f * agree, 0.f, 1.f);
                 const float fusion = d_g_det ? (d_on_det ? f_both : d_gq * 0.6f) : (d_on_det ? (float)(HOT(c.radar_quality64) * 0.5) : 0.f);
-                if (!fresh_k) {
-                    // bit 7: a delayed onboard sample exists (core.py:576-593): info['radar_quality'] is the configured quality then,
-                    // detected or not, and 0.0 only while the delay line is still filling
+                // bit 7: a delayed onboard sample exists (core.py:576-593): info['radar_quality'] is the configured quality then,
+                // detected or not, and 0.0 only while the delay line is still filling
+                // (a reset-only launch reports the detections of the FIRST observation: reset()'s info, environment.py:595-601)
+                if (MODE == 1 || !fresh_k)
                     det_bits = (d_on_det ? 32u : 0u) | (d_g_det ? 64u : 0u) | ((HOT(c.o_delay) == 0 || steps >= on_delay) ? 128u : 0u);
+                if (!fresh_k) {
                     if (HAS(HLX_F_RADAR_DEBUG) && (slots & (1u << 20)) && HOT(opt.info.radar_debug)) {     // what info['radar_debug'] (core.py:650-683) cannot rebuild from positions
                         auto rd = G(HOT(opt.info.radar_debug)) + i;
                         rd[0] = q.w; rd[N] = q.x; rd[2 * N] = q.y; rd[3 * N] = q.z;
@@ -1846,6 +1848,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
         // complete now that pass 0 has decided the detections
         if (MODE == 0 && HLX_INFO_W2 == 0 && (slots & (1u << 23)) != 0u)
             wt16i(rsI, (uint32_t)i * 16u, (uint32_t)n * 32u, make_float4(mpos.x, mpos.y, mpos.z, __uint_as_float(info_word | det_bits)));
+        // reset()'s info (environment.py:595-601: missile_pos, interceptor_pos, distance, radar_detected, radar_quality) in the words a
+        // step writes, for the environments this launch resets -- hlx_reset_info
+        if (MODE == 1 && (slots & (1u << 23)) != 0u && done) {
+            const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)HOT(opt.info.packed), 0, 0x7FFFFFFF, 0x00020000);
+            const uint32_t alive = HAS(HLX_F_VOLLEY) ? (uint32_t)VK : 1u;      // nothing intercepted, every missile of the volley in flight
+            wt16i(rsR, (uint32_t)i * 16u, 0u, make_float4(prev_distance, min_distance, fuel, 0.f));
+            wt16i(rsR, (uint32_t)i * 16u, (uint32_t)n * 16u, make_float4(ipos.x, ipos.y, ipos.z, __int_as_float(0)));
+            wt16i(rsR, (uint32_t)i * 16u, (uint32_t)n * 32u, make_float4(mpos.x, mpos.y, mpos.z, __uint_as_float(det_bits | (alive << 12))));
+        }
 #if HLX_FRESH_TRIP
         if (RARE(again)) trip(std::true_type{});
 #else

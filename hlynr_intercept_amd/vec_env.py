@@ -115,6 +115,9 @@ class LazyInfos(Sequence):
             # environment.py:848: per-missile closest approach in volley mode, [distance] otherwise
             "missile_min_distances": (h["missile_min_distances"][:h["volley"][1], i].tolist() if "missile_min_distances" in h
                                       else [float(h["distance"][i])]),
+            # environment.py:852-856: configuration echoed into every info
+            "precision_mode": h["constants"][0], "proximity_fuze_enabled": h["constants"][1],
+            "proximity_kill_radius": h["constants"][2],
         }
         row = self._done.get(i)
         rd = h.get("radar")
@@ -140,6 +143,25 @@ class LazyInfos(Sequence):
     def done_items(self):
         """(env index, info dict) for the envs that finished this step - what callbacks iterate over."""
         return [(i, self[i]) for i in sorted(self._done)]
+
+
+class _ResetInfos(Sequence):
+    """SB3's `VecEnv.reset_infos` after a reset: per environment the dict reset() returns in the reference (environment.py:595-601),
+    built when indexed from a host snapshot of the words hlx_reset_info wrote."""
+
+    def __init__(self, packed_host, radar_quality):
+        self._pk, self._q = packed_host, float(radar_quality)
+
+    def __len__(self):
+        return self._pk.shape[1]
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        pk = self._pk.numpy()
+        flags = int(pk.view(np.uint8)[2, i, 12])
+        return {"missile_pos": pk[2, i, 0:3].copy(), "interceptor_pos": pk[1, i, 0:3].copy(), "distance": float(pk[0, i, 0]),
+                "radar_detected": bool(flags & 32), "radar_quality": self._q if flags & 128 else 0.0}
 
 
 class _InfoView(Mapping):
@@ -264,6 +286,9 @@ class HlynrVecEnv(_SB3VecEnv):
                                          radar_debug=self.info["radar_debug"].data_ptr() if radar_debug else None,
                                          packed=pk.data_ptr())
         self._info_ref = C.byref(self._info_soa)
+        # reset()'s info (environment.py:595-601) lands in the same words, for the environments a reset touches (hlx_reset_info)
+        self._info_reset = _lib.HlxInfoSoa(packed=self.info_packed.data_ptr())
+        self._info_reset_ref = C.byref(self._info_reset)
         self._ptr_done_idx = self.done_idx.data_ptr()
         self._step_ptrs = (self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(), self.truncated.data_ptr(),
                            self.terminal_obs.data_ptr())
@@ -310,12 +335,15 @@ class HlynrVecEnv(_SB3VecEnv):
     # ------------------------------------------------------------------ torch / gymnasium-vector style API
     def reset_torch(self, mask=None, obs_ptr: Optional[int] = None):
         """Reset all envs (or those where `mask` is non-zero); returns the device obs tensor [N, 26].
-        `obs_ptr`: raw device address to write the observations to instead (the frame ring of wrappers.py)."""
+        `obs_ptr`: raw device address to write the observations to instead (the frame ring of wrappers.py).
+        `self.info` of the environments that were reset holds reset()'s info afterwards (environment.py:595-601: positions, spawn
+        distance, the first observation's detections; every other key as a new episode has it)."""
         mptr = None
         if mask is not None:
             mask = mask.to(device=self.device, dtype=self._torch.uint8).contiguous()
             mptr = mask.data_ptr()
-        _lib.check(self._lib.hlx_reset(self._h, mptr, obs_ptr if obs_ptr is not None else self.obs.data_ptr(), self._stream()))
+        _lib.check(self._lib.hlx_reset_info(self._h, mptr, obs_ptr if obs_ptr is not None else self.obs.data_ptr(),
+                                            self._info_reset_ref, self._stream()))
         return self.obs
 
     def step_torch(self, actions, want_done_list: bool = False, obs_ptr: Optional[int] = None):
@@ -381,7 +409,12 @@ class HlynrVecEnv(_SB3VecEnv):
         if seed is not None:
             self.seed(seed)
         self._t_start = time.time()
-        return self.reset_torch().cpu().numpy()
+        obs = self.reset_torch()
+        pk_h = self._torch.empty(self.info_packed.shape, dtype=self.info_packed.dtype, device="cpu", pin_memory=True)
+        pk_h.copy_(self.info_packed, non_blocking=True)
+        out = obs.cpu().numpy()                      # (synchronises: the snapshot above has landed too)
+        self.reset_infos = _ResetInfos(pk_h, self.rc.radar_quality)
+        return out
 
     def _apply_volley_options(self, options):
         # environment.py:364-365: options.get(key, config default) -- a key that is absent falls back to the CONFIG's value
@@ -457,6 +490,7 @@ class HlynrVecEnv(_SB3VecEnv):
         dones = term_h | trunc_h
         n_done = int(plane("n_done")[parity])
         host = dict(terminated=term_h, truncated=trunc_h, t_start=self._t_start, radar_quality=self.rc.radar_quality,
+                    constants=(bool(self.rc.precision_mode), bool(self.rc.proximity_fuze), float(self.rc.proximity_kill_radius)),
                     volley=(bool(self.rc.volley_mode), int(self.rc.volley_size) if self.rc.volley_mode else 1))
         pk = plane("packed")
         host.update(self._unpack_info(pk, pk.view(np.int32), pk.view(np.uint8)))

@@ -211,6 +211,11 @@ int hlx_destroy(hlx_env *env);
 /* environment.py:353 reset().  mask: device uint8[N] (non-zero = reset that env) or NULL = all.
  * obs_out: device float[N][26] (rows of envs that are not reset are left untouched), may be NULL. */
 int hlx_reset(hlx_env *env, const uint8_t *mask, float *obs_out, void *stream);
+/* ... and reset()'s info with it (environment.py:595-601: missile_pos, interceptor_pos, distance, radar_detected, radar_quality): for the
+ * environments being reset, info->packed (the only form accepted here) receives the words a step would write -- distance = min_distance
+ * = the spawn distance, full fuel, nothing used, steps 0, both positions, and in the flag byte the detections of the FIRST observation
+ * (bits 5-7; every other flag clear), missiles = none intercepted / all in flight.  Other environments' words are left alone. */
+int hlx_reset_info(hlx_env *env, const uint8_t *mask, float *obs_out, const hlx_info_soa *info, void *stream);
 
 /* Explicit resets and the random streams.  The spawn draws of an hlx_reset are Philox(seed, global env id, clock | epoch << 48):
  * `epoch` counts the hlx_reset calls this HANDLE has seen at the current clock value (it restarts at 0 whenever a step

@@ -182,8 +182,21 @@ def _replay_fixture(name, radar):
     env.set_noise(sn_all[0], rn0)
     obs0 = env.reset_torch().cpu().numpy()
     assert np.max(_obs_err(obs0, fx["reset_obs0"][None])) <= OBS_ATOL
-    # forced edge cases: overwrite the kinematic state the generator tweaked after its first reset
     st = env.get_state()
+    # reset()'s info (environment.py:595-601) in the words hlx_reset_info wrote: the spawn the state holds, nothing used, no flag
+    # but the first observation's detections -- and no onboard detection while a delay line is still filling (core.py:576-583)
+    for i in range(n):
+        assert np.array_equal(env.info["interceptor_pos"][:, i].cpu().numpy(), np.array(st[i].int_pos[:], np.float32))
+        assert np.array_equal(env.info["missile_pos"][:, i].cpu().numpy(), np.array(st[i].mis_pos[:], np.float32))
+        assert float(env.info["distance"][i]) == float(st[i].prev_distance) == float(env.info["min_distance"][i])
+        assert float(env.info["fuel"][i]) == float(st[i].fuel) and float(env.info["fuel_used"][i]) == 0.0 and int(env.info["steps"][i]) == 0
+        fl = int(env.info["flags"][i])
+        assert fl & 0x1F == 0 and bool(fl & 128) == (int(st[i].on_delay) == 0), (fl, int(st[i].on_delay))
+        if int(st[i].on_delay) > 0:
+            assert not fl & 32
+        K = int(rc.volley_size) if rc.volley_mode else 1
+        assert int(env.info["missiles"][i]) == K << 4
+    # forced edge cases: overwrite the kinematic state the generator tweaked after its first reset
     for i in range(n):
         for fld in ("int_pos", "int_vel", "int_quat", "mis_pos", "mis_vel"):
             arr = getattr(st[i], fld)

@@ -831,3 +831,41 @@ def test_next_episode_pool_under_a_curriculum_that_moves_every_step(ramp):
         # suspended while the reliabilities moved (~76 steps + 16 quiet ones), filled once when they had settled
         assert 70 <= st["suspended_steps"] <= 100 and st["full_fills"] == 2, st
     on.close(); off.close()
+
+
+@pytest.mark.parametrize("physics", ["base", "v2dr"])
+def test_reset_returns_the_reference_s_reset_info_and_a_masked_reset_touches_only_its_environments(physics):
+    """reset()'s info (environment.py:595-601: missile_pos, interceptor_pos, distance, radar_detected, radar_quality) for every
+    environment a reset touches -- `reset_infos` (SB3) and the info planes (hlx_reset_info) -- and nobody else's."""
+    import torch
+    n = 300
+    env = _env(n, physics=physics, over={"max_steps": 50})
+    env.reset()
+    st = env.get_state()
+    assert len(env.reset_infos) == n
+    for i in (0, 63, 64, 299):
+        ri = env.reset_infos[i]
+        assert set(ri) == {"missile_pos", "interceptor_pos", "distance", "radar_detected", "radar_quality"}
+        assert np.array_equal(ri["missile_pos"], np.array(st[i].mis_pos[:], np.float32))
+        assert np.array_equal(ri["interceptor_pos"], np.array(st[i].int_pos[:], np.float32))
+        assert ri["distance"] == float(st[i].prev_distance)
+        if physics == "v2dr":      # 30 ms onboard delay line still filling: no delayed sample yet (core.py:576-583)
+            assert ri["radar_detected"] is False and ri["radar_quality"] == 0.0
+        else:
+            assert ri["radar_quality"] == env.rc.radar_quality
+    if physics == "base":          # a new episode looks straight at its missile: most are detected at once
+        assert sum(env.reset_infos[i]["radar_detected"] for i in range(n)) > n // 2
+    g = torch.Generator(device=env.device).manual_seed(1)
+    for _ in range(7):
+        env.step_torch(torch.rand((n, 6), generator=g, device=env.device) * 2 - 1)
+    before = {k: env.info[k].clone() for k in ("distance", "steps", "flags", "fuel_used", "missile_pos")}
+    mask = (torch.arange(n, device=env.device) % 3 == 0).to(torch.uint8)
+    env.reset_torch(mask)
+    m = mask.bool()
+    assert torch.equal(env.info["steps"][~m], before["steps"][~m]) and bool((env.info["steps"][m] == 0).all())
+    assert torch.equal(env.info["distance"][~m], before["distance"][~m]) and torch.equal(env.info["missile_pos"][:, ~m], before["missile_pos"][:, ~m])
+    assert bool((env.info["fuel_used"][m] == 0).all()) and bool((env.info["fuel_used"][~m] > 0).all())
+    st = env.get_state()
+    for i in (0, 3, 297):
+        assert float(env.info["distance"][i]) == float(st[i].prev_distance) and int(st[i].steps) == 0
+    env.close()
