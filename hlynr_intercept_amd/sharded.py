@@ -163,9 +163,14 @@ class ShardedHlynrVecEnv(_SB3VecEnv):
         obs = self.reset_torch()
         import time
         now = time.time()
-        for s in self.shards:
+        snaps, outs = [], []
+        for k, s in enumerate(self.shards):
             s._t_start = now
-        return np.concatenate([o.cpu().numpy() for o in obs], axis=0)
+            with self._on(k):
+                snaps.append(s._snapshot_reset_infos())
+                outs.append(obs[k].cpu().numpy())              # (synchronises shard k's stream: its snapshot has landed too)
+        self.reset_infos = _ShardedInfos(snaps, self.offsets)      # reset()'s info per environment (environment.py:595-601)
+        return np.concatenate(outs, axis=0)
 
     def step_async(self, actions):
         if self._pending is not None:

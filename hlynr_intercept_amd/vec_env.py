@@ -158,6 +158,10 @@ class _ResetInfos(Sequence):
     def __getitem__(self, i):
         if isinstance(i, slice):
             return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
         pk = self._pk.numpy()
         flags = int(pk.view(np.uint8)[2, i, 12])
         return {"missile_pos": pk[2, i, 0:3].copy(), "interceptor_pos": pk[1, i, 0:3].copy(), "distance": float(pk[0, i, 0]),
@@ -410,11 +414,14 @@ class HlynrVecEnv(_SB3VecEnv):
             self.seed(seed)
         self._t_start = time.time()
         obs = self.reset_torch()
+        self.reset_infos = self._snapshot_reset_infos()
+        return obs.cpu().numpy()                     # (synchronises: the snapshot has landed too)
+
+    def _snapshot_reset_infos(self):
+        """Enqueue the host copy of the words hlx_reset_info wrote (valid after the stream's next synchronisation)."""
         pk_h = self._torch.empty(self.info_packed.shape, dtype=self.info_packed.dtype, device="cpu", pin_memory=True)
         pk_h.copy_(self.info_packed, non_blocking=True)
-        out = obs.cpu().numpy()                      # (synchronises: the snapshot above has landed too)
-        self.reset_infos = _ResetInfos(pk_h, self.rc.radar_quality)
-        return out
+        return _ResetInfos(pk_h, self.rc.radar_quality)
 
     def _apply_volley_options(self, options):
         # environment.py:364-365: options.get(key, config default) -- a key that is absent falls back to the CONFIG's value

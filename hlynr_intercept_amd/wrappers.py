@@ -247,7 +247,9 @@ class _DeviceObsWrapper(_SB3VecEnv):
     def reset(self):
         import time
         self._base._t_start = time.time()
-        return self.reset_torch().cpu().numpy()
+        obs = self.reset_torch()
+        self.reset_infos = self._base.reset_infos = self._base._snapshot_reset_infos()      # reset()'s info (environment.py:595-601)
+        return obs.cpu().numpy()
 
     def step_async(self, actions):
         if self._pending is not None:

@@ -85,6 +85,11 @@ def test_sharded_sb3_numpy_api_concatenates_on_the_host():
     sh = ShardedHlynrVecEnv(_cfg(), num_envs=n, devices=[0, 0], seed=8)
     o1, o2 = whole.reset(), sh.reset()
     assert o2.shape == (n, 26) and np.array_equal(o1, o2)
+    assert len(sh.reset_infos) == len(whole.reset_infos) == n            # reset()'s info (environment.py:595-601), shard by shard
+    for i in (0, 149, 150, 299, -1):
+        a, b = whole.reset_infos[i], sh.reset_infos[i]
+        assert set(a) == set(b) and a["distance"] == b["distance"] and a["radar_detected"] == b["radar_detected"]
+        assert np.array_equal(a["missile_pos"], b["missile_pos"]) and np.array_equal(a["interceptor_pos"], b["interceptor_pos"])
     rng = np.random.default_rng(1)
     seen = 0
     for t in range(40):
