@@ -28,6 +28,13 @@ CHECKS = textwrap.dedent('''
     plain.seed(123); ref = plain.reset_torch()
     assert torch.is_tensor(obs) and obs.is_cuda and obs.shape == (n, 26) and torch.equal(obs, ref)
     assert torch.equal(info["distance"], plain.info["distance"]) and info["interceptor_pos"].shape == (n, 3)
+    # reset()'s info is the new episode's (environment.py:595-601; hlx_reset_info), not whatever the planes held before
+    st = plain.get_state()
+    for i in (0, 77, n - 1):
+        assert float(info["distance"][i]) == float(st[i].prev_distance) > 0 and int(info["steps"][i]) == 0
+        assert info["missile_pos"][i].tolist() == [float(x) for x in st[i].mis_pos] and info["interceptor_pos"][i].tolist() == [float(x) for x in st[i].int_pos]
+    assert info["radar_quality"].shape == (n,) and bool((info["radar_quality"] == plain.rc.radar_quality).all())      # base physics: no delay line
+    assert info["radar_detected"].dtype == torch.bool and not bool(info["intercepted"].any())
     g = torch.Generator(device=obs.device).manual_seed(0)
     finished = 0
     for t in range(60):
