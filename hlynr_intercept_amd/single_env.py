@@ -17,8 +17,10 @@ spaces, same info keys (environment.py:829-857, `radar_debug` included: core.py:
 Two things differ from the reference, both by construction of the batched step:
   * **No auto-reset is visible.**  The kernel starts the next episode inside the launch in which one ends (VecEnv semantics);
     here `step()` returns the TERMINAL observation of the finished episode, as `gym.Env.step` does, and `reset()` draws the
-    episode that follows (one reset-only launch, whose info words hold reset()'s own info: hlx_reset_info).  Stepping a finished
-    environment without `reset()` continues the episode the kernel started -- the reference's behaviour there is undefined.
+    episode that follows (one reset-only launch, whose info words hold reset()'s own info: hlx_reset_info).  Between the two,
+    `interceptor_state` / `missile_state` hold what the step's info keeps of the FINAL state (positions, fuel); the final velocity
+    and orientation are not kept and asking for them raises.  Stepping a finished environment without `reset()` continues the
+    episode the kernel started -- the reference's behaviour there is undefined.
   * **Random streams.**  `reset(seed=s)` keys the counter-based generator (Philox: seed, environment id, episode / clock) instead of
     `np.random.seed(s)`: the same seed gives the same episodes run after run, not the reference's particular draws (DESIGN.md
     section 2: parity with the reference's arithmetic is established on injected draws).  Without a seed the key comes from the
@@ -43,6 +45,14 @@ try:  # the reference subclasses gym.Env (environment.py:15); gymnasium is optio
 except Exception:  # pragma: no cover - gymnasium is absent in the build container
     _GymEnv = object
 
+class _EndState(dict):
+    """`interceptor_state` / `missile_state` after the step that ended an episode: the keys the step's info still holds."""
+
+    def __missing__(self, key):
+        raise KeyError(f"{key!r} of the state an episode ended in is not kept: the batched step starts the next episode in the same "
+                       f"launch (read it before the terminal step, or use info['interceptor_pos'] / info['missile_pos'])")
+
+
 class InterceptEnvironment(_GymEnv):
     """One intercept environment stepped on the GPU; `rl_system/environment.py:15-859` from the outside."""
 
@@ -65,6 +75,7 @@ class InterceptEnvironment(_GymEnv):
         self.target_position = np.asarray(rc.target_pos, np.float32)        # environment.py:39
         self.steps, self.total_fuel_used = 0, 0.0                                # environment.py:203-204
         self._needs_reset = True
+        self._final = None                       # what is known of the state an episode ended in (see interceptor_state)
         self._actions = np.zeros((1, 6), np.float32)
 
     # ------------------------------------------------------------------ gym.Env
@@ -81,7 +92,7 @@ class InterceptEnvironment(_GymEnv):
                 "distance": float(v.info["distance"][0].item()),
                 "radar_detected": bool(flags & 32),
                 "radar_quality": float(v.rc.radar_quality) if flags & 128 else 0.0}
-        self._needs_reset = False
+        self._needs_reset, self._final = False, None
         self.steps, self.total_fuel_used = 0, 0.0
         return obs, info
 
@@ -103,6 +114,8 @@ class InterceptEnvironment(_GymEnv):
             # observation of the episode it has already started
             out = np.asarray(info.pop("terminal_observation"), np.float32).copy()
             info.pop("episode", None)                    # (SB3's Monitor key)
+            self._final = (_EndState(position=info["interceptor_pos"].copy(), fuel=float(info["fuel_remaining"])),
+                           _EndState(position=info["missile_pos"].copy()))
         return out, float(rew[0]), terminated, truncated, info
 
     def close(self):
@@ -128,11 +141,15 @@ class InterceptEnvironment(_GymEnv):
 
     @property
     def interceptor_state(self) -> Dict[str, Any]:                               # environment.py:201 (debug_pn_guidance.py:77-80)
-        return self._current("interceptor_state")
+        """{'position', 'velocity', 'orientation', 'fuel'}.  Between the step that ended an episode and the next reset(): the FINAL
+        position and fuel (what scripts/eval_terminal_360.py:91-103 reads for the miss distance); the final velocity and orientation
+        are gone -- the kernel has started the next episode in their place -- and asking for them raises instead of answering with
+        the next episode's."""
+        return self._final[0] if self._final is not None else self._current("interceptor_state")
 
     @property
     def missile_state(self) -> Dict[str, Any]:                                   # environment.py:200
-        return self._current("missile_state")
+        return self._final[1] if self._final is not None else self._current("missile_state")
 
     @property
     def missile_states(self) -> List[Dict[str, Any]]:                            # environment.py:44 (volley mode: one dict per missile)
@@ -160,8 +177,6 @@ class InterceptEnvironment(_GymEnv):
 
     # ------------------------------------------------------------------ helpers
     def _state(self):
-        """The environment's state struct (hlx_env_state).  After an episode has ended the arena already holds the NEXT episode:
-        the dicts then describe its start, as the reference's attributes do right after reset()."""
         return self._venv.get_state()[0]
 
     def _current(self, name):

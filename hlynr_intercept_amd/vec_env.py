@@ -95,37 +95,39 @@ class LazyInfos(Sequence):
         if not 0 <= i < self._n:
             raise IndexError(i)
         h = self._h
-        flags = int(h["flags"][i])
+        row = self._done.get(i)
+        # a finished environment's values came over with the step (compact rows); anybody else's are fetched when first asked for
+        s, j = (h["done"], row) if row is not None else (h["full"](), i)
+        flags = int(s["flags"][j])
         d: Dict[str, Any] = {
-            "distance": float(h["distance"][i]), "min_distance": float(h["min_distance"][i]),
-            "fuel_remaining": float(h["fuel"][i]), "intercepted": bool(flags & 1),
+            "distance": float(s["distance"][j]), "min_distance": float(s["min_distance"][j]),
+            "fuel_remaining": float(s["fuel"][j]), "intercepted": bool(flags & 1),
             "missile_hit_target": bool(flags & 2), "proximity_fuze_triggered": bool(flags & 4),
             "clamped": bool(flags & 8), "crossed_threshold": bool(flags & 16), "radar_detected": bool(flags & 32),
             "ground_radar_detected": bool(flags & 64),
             "TimeLimit.truncated": bool(h["truncated"][i] and not h["terminated"][i]),
             # environment.py:844-847
             "volley_mode": h["volley"][0], "volley_size": h["volley"][1],
-            "missiles_intercepted": int(h["missiles"][i]) & 15, "missiles_remaining": int(h["missiles"][i]) >> 4,
+            "missiles_intercepted": int(s["missiles"][j]) & 15, "missiles_remaining": int(s["missiles"][j]) >> 4,
             # environment.py:836-841 (read by train_hrl_pretrain.py:180-198, inference.py:535-560)
-            "interceptor_pos": h["interceptor_pos"][:, i].copy(), "missile_pos": h["missile_pos"][:, i].copy(),
+            "interceptor_pos": s["interceptor_pos"][:, j].copy(), "missile_pos": s["missile_pos"][:, j].copy(),
             # fuel_used: the reference's `total_fuel_used` (environment.py:886), accumulated step by step in float32 by the kernel
-            "steps": int(h["steps"][i]), "fuel_used": float(h["fuel_used"][i]),
+            "steps": int(s["steps"][j]), "fuel_used": float(s["fuel_used"][j]),
             # environment.py:840 <- core.py:536,584: the configured quality whenever a delayed onboard sample exists
             "radar_quality": float(h["radar_quality"]) if flags & 128 else 0.0,
             # environment.py:848: per-missile closest approach in volley mode, [distance] otherwise
-            "missile_min_distances": (h["missile_min_distances"][:h["volley"][1], i].tolist() if "missile_min_distances" in h
-                                      else [float(h["distance"][i])]),
+            "missile_min_distances": (s["missile_min_distances"][:h["volley"][1], j].tolist() if "missile_min_distances" in s
+                                      else [float(s["distance"][j])]),
             # environment.py:852-856: configuration echoed into every info
             "precision_mode": h["constants"][0], "proximity_fuze_enabled": h["constants"][1],
             "proximity_kill_radius": h["constants"][2],
         }
-        row = self._done.get(i)
         rd = h.get("radar")
         if rd is not None:   # environment.py:842
-            p = rd["planes"]
-            d["radar_debug"] = radar_debug(rd["rc"], rd["beam_width"], d["interceptor_pos"], d["missile_pos"], p[0:4, i],
-                                           float(p[4, i]), int(p[5, i:i + 1].view(np.int32)[0]), flags, float(p[6, i]),
-                                           float(p[7, i]))
+            p = s["radar_planes"]
+            d["radar_debug"] = radar_debug(rd["rc"], rd["beam_width"], d["interceptor_pos"], d["missile_pos"], p[0:4, j],
+                                           float(p[4, j]), int(p[5, j:j + 1].view(np.int32)[0]), flags, float(p[6, j]),
+                                           float(p[7, j]))
         if row is not None:
             d["terminal_observation"] = h["terminal_obs"][row]
             d["episode"] = {"r": float(h["ep_return"][row]), "l": int(h["ep_length"][row]),
@@ -265,6 +267,8 @@ class HlynrVecEnv(_SB3VecEnv):
             self._slab_layout[name] = (off, nbytes, dt, shape)
             off += (nbytes + 255) // 256 * 256
         self._slab = torch.zeros(off, dtype=u8, device=dev)
+        self._slab_head = self._slab_layout["packed"][0]      # bytes in front of the info words: what every step brings to the host
+        self._info_gen = 0                                    # counts the launches that rewrite info words (LazyInfos validity)
         v = {name: self._slab[o:o + nb].view(dt).view(shape) for name, (o, nb, dt, shape) in self._slab_layout.items()}
         self.reward, self.terminated, self.truncated = v["reward"], v["terminated"], v["truncated"]
         # the kernel counts finished environments straight into the slab (element `vec-step clock & 1`): no copy per step
@@ -346,6 +350,7 @@ class HlynrVecEnv(_SB3VecEnv):
         if mask is not None:
             mask = mask.to(device=self.device, dtype=self._torch.uint8).contiguous()
             mptr = mask.data_ptr()
+        self._info_gen += 1
         _lib.check(self._lib.hlx_reset_info(self._h, mptr, obs_ptr if obs_ptr is not None else self.obs.data_ptr(),
                                             self._info_reset_ref, self._stream()))
         return self.obs
@@ -358,6 +363,7 @@ class HlynrVecEnv(_SB3VecEnv):
         overwritten by the next call (clone what must survive)."""
         actions, di, nd = self._step_args(actions, want_done_list)
         p = self._step_ptrs
+        self._info_gen += 1
         _lib.check(self._lib.hlx_step(self._h, actions.data_ptr(), obs_ptr if obs_ptr is not None else p[0], p[1], p[2], p[3], p[4],
                                       di, nd, self._info_ref, self._stream()))
         return self.obs, self.reward, self.terminated, self.truncated, self._step_info(want_done_list)
@@ -388,6 +394,7 @@ class HlynrVecEnv(_SB3VecEnv):
         (open-loop evaluation / benchmark path).  Returns (obs, reward, terminated, truncated) ring buffers."""
         t = self._torch
         T = int(action_tape.shape[0])
+        self._info_gen += 1
         assert tuple(action_tape.shape[1:]) == (self.num_envs, _lib.ACT_DIM) and action_tape.dtype == t.float32
         assert action_tape.is_contiguous() and action_tape.device == self.device
         key = ("ro", out_slots)
@@ -474,23 +481,32 @@ class HlynrVecEnv(_SB3VecEnv):
             h.copy_(t, non_blocking=True)
             return h
 
-        # the slab (every per-step scalar plane) in one copy, the observation batch in another; a wrapper's own reward /
-        # done tensors (e.g. normalised rewards) are fetched separately
-        slab_h, obs_t = d2h(self._slab), d2h(obs)
+        # the head of the slab (reward, flags, the done counter) in one copy, the observation batch in another; a wrapper's own
+        # reward / done tensors (e.g. normalised rewards) are fetched separately.  The info words -- 48 of the 174 bytes per
+        # environment and step this path used to bring over -- follow for the finished environments only (compact rows, below);
+        # the others' are fetched when somebody indexes such an environment's info (SB3's loops never do: they look at the
+        # `episode` / `terminal_observation` / `TimeLimit.truncated` keys of finished ones).
+        head_h, obs_t = d2h(self._slab[:self._slab_head]), d2h(obs)
         own = {name: d2h(t) for name, t, mine in (("reward", rew, self.reward), ("terminated", term, self.terminated),
                                                    ("truncated", trunc, self.truncated)) if t.data_ptr() != mine.data_ptr()}
-        return slab_h, obs_t, own, terminal, torch.cuda.current_stream(self.device), int(self._lib.hlx_vec_steps(self._h)) & 1
+        return head_h, obs_t, own, terminal, torch.cuda.current_stream(self.device), int(self._lib.hlx_vec_steps(self._h)) & 1, self._info_gen
 
     def _materialise_end(self, ticket):
-        slab_h, obs_t, own, terminal, stream, parity = ticket
+        head_h, obs_t, own, terminal, stream, parity, gen = ticket
+        torch = self._torch
         stream.synchronize()
-        slab_np = slab_h.numpy()
+        head_np = head_h.numpy()
 
-        def plane(name):
+        def plane(name, buf=None, base=0):
             if name in own:
                 return own[name].numpy()
             o, nb, dt, shape = self._slab_layout[name]
-            return slab_np[o:o + nb].view(_NP_DTYPES[dt]).reshape(shape)
+            return (head_np if buf is None else buf)[o - base:o - base + nb].view(_NP_DTYPES[dt]).reshape(shape)
+
+        def views(pk, extra):
+            v = self._unpack_info(pk, pk.view(np.int32), pk.view(np.uint8))
+            v.update(extra)
+            return v
 
         obs_h, rew_h = obs_t.numpy(), plane("reward")
         term_h, trunc_h = plane("terminated").astype(bool), plane("truncated").astype(bool)
@@ -499,20 +515,42 @@ class HlynrVecEnv(_SB3VecEnv):
         host = dict(terminated=term_h, truncated=trunc_h, t_start=self._t_start, radar_quality=self.rc.radar_quality,
                     constants=(bool(self.rc.precision_mode), bool(self.rc.proximity_fuze), float(self.rc.proximity_kill_radius)),
                     volley=(bool(self.rc.volley_mode), int(self.rc.volley_size) if self.rc.volley_mode else 1))
-        pk = plane("packed")
-        host.update(self._unpack_info(pk, pk.view(np.int32), pk.view(np.uint8)))
-        if "missile_min_distances" in self._slab_layout:
-            host["missile_min_distances"] = plane("missile_min_distances")
-        if "radar_debug" in self._slab_layout:
-            host["radar"] = dict(planes=plane("radar_debug"), rc=self.rc, beam_width=self.curriculum()["beam_width"])
+        volley, radar = "missile_min_distances" in self._slab_layout, "radar_debug" in self._slab_layout
+        if radar:
+            host["radar"] = dict(rc=self.rc, beam_width=self.curriculum()["beam_width"])
+        cache = {}
+
+        def full():
+            """Every environment's info words of THIS step, fetched once, on first use -- valid until the next step or reset."""
+            if "v" not in cache:
+                if gen != self._info_gen:
+                    raise RuntimeError("the info of an environment that did not finish was first read after a later step() / reset(): "
+                                       "index `infos` before stepping again (finished environments' infos stay valid)")
+                with torch.cuda.stream(stream):
+                    tail = self._slab[self._slab_head:].cpu().numpy()
+                extra = {}
+                if volley:
+                    extra["missile_min_distances"] = plane("missile_min_distances", tail, self._slab_head)
+                if radar:
+                    extra["radar_planes"] = plane("radar_debug", tail, self._slab_head)
+                cache["v"] = views(plane("packed", tail, self._slab_head), extra)
+            return cache["v"]
+
+        host["full"] = full
         done_rows: Dict[int, int] = {}
         if n_done:
-            with self._torch.cuda.stream(stream):
-                idx = self.done_idx[:n_done].to(self._torch.int64)
+            with torch.cuda.stream(stream):
+                idx = self.done_idx[:n_done].to(torch.int64)
                 idx_h = idx.cpu().numpy()
                 host["terminal_obs"] = terminal.index_select(0, idx).cpu().numpy()
                 host["ep_return"] = self.info["episode_return"].index_select(0, idx).cpu().numpy()
                 host["ep_length"] = self.info["episode_length"].index_select(0, idx).cpu().numpy()
+                extra = {}
+                if volley:
+                    extra["missile_min_distances"] = self.info["missile_min_distances"].index_select(1, idx).cpu().numpy()
+                if radar:
+                    extra["radar_planes"] = self.info["radar_debug"].index_select(1, idx).cpu().numpy()
+                host["done"] = views(self.info_packed.index_select(1, idx).cpu().numpy(), extra)
             done_rows = {int(e): r for r, e in enumerate(idx_h)}
         return obs_h, rew_h, dones, LazyInfos(self.num_envs, done_rows, host)
 

@@ -227,6 +227,7 @@ class _DeviceObsWrapper(_SB3VecEnv):
         # pipeline's frame ring) and the pipeline's launches behind it
         actions, di, nd = b._step_args(actions, want_done_list)
         rew, term, trunc = b.reward, b.terminated, b.truncated
+        b._info_gen += 1
         _lib.check(self._lib.hlx_obs_step(self._p, b._h, actions.data_ptr(), rew.data_ptr(), term.data_ptr(), trunc.data_ptr(),
                                           b.terminal_obs.data_ptr(), di, nd, C.byref(b._info_soa), self.stacked.data_ptr(),
                                           self.terminal_stacked.data_ptr(), self.reward_out.data_ptr(), b._stream()))

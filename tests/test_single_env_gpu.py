@@ -44,6 +44,11 @@ def test_single_environment_speaks_gym_env_with_the_reference_s_keys_and_types()
         assert info["steps"] == env.steps == t and info["fuel_used"] == env.total_fuel_used > 0
         done = term or trunc
     assert t <= 40 and (trunc or term)
+    # between the terminal step and reset(): the state the episode ENDED in, as far as it is kept -- never the next episode's
+    assert np.array_equal(env.interceptor_state["position"], info["interceptor_pos"]) and env.interceptor_state["fuel"] == info["fuel_remaining"]
+    assert np.array_equal(env.missile_state["position"], info["missile_pos"])
+    with pytest.raises(KeyError):
+        env.interceptor_state["velocity"]
     obs2, info2 = env.reset()
     assert set(info2) == RESET_KEYS and env.steps == 0 and not np.array_equal(obs2, obs)
     env.set_training_step_count(1234)

@@ -869,3 +869,41 @@ def test_reset_returns_the_reference_s_reset_info_and_a_masked_reset_touches_onl
     for i in (0, 3, 297):
         assert float(env.info["distance"][i]) == float(st[i].prev_distance) and int(st[i].steps) == 0
     env.close()
+
+
+def test_numpy_path_brings_info_words_over_for_finished_environments_only_and_on_request_for_the_rest():
+    """`step_wait()` copies reward / flags / observations, and the info words of FINISHED environments; another environment's info
+    is fetched when it is first indexed -- the same values as the device planes -- and refuses to be read for the first time
+    once a later step has overwritten them."""
+    import torch
+    n = 500
+    env = _env(n, physics="base", over={"max_steps": 17})
+    env.reset()
+    rng = np.random.default_rng(2)
+    kept = None
+    for t in range(40):
+        obs, rew, dones, infos = env.step(rng.uniform(-1, 1, (n, 6)).astype(np.float32))
+        dist, steps, flags = env.info["distance"].cpu().numpy(), env.info["steps"].cpu().numpy(), env.info["flags"].cpu().numpy()
+        for i, info in infos.done_items():                    # compact rows
+            assert info["distance"] == float(dist[i]) and info["steps"] == int(steps[i]) and info["intercepted"] == bool(flags[i] & 1)
+            assert np.array_equal(info["missile_pos"], env.info["missile_pos"][:, i].cpu().numpy())
+        if not dones.all():                                     # (at max_steps the whole batch finishes together)
+            live = int(np.nonzero(~dones)[0][0])
+            li = infos[live]                                    # fetched now
+            assert li["distance"] == float(dist[live]) and li["steps"] == int(steps[live]) and "episode" not in li
+            assert np.array_equal(li["interceptor_pos"], env.info["interceptor_pos"][:, live].cpu().numpy())
+        if t == 20:
+            kept = infos
+    assert kept is not None
+    done_then = [i for i, _ in kept.done_items()]
+    fresh = _env(8)                                             # an `infos` whose live rows were never fetched ...
+    fresh.reset()
+    a = np.zeros((8, 6), np.float32)
+    _, _, _, old = fresh.step(a)
+    fresh.step(a)
+    with pytest.raises(RuntimeError):
+        old[0]                                                  # ... is first read after a later step: refused, not answered with that step's values
+    fresh.close()
+    if done_then:
+        assert kept[done_then[0]]["episode"]["l"] > 0           # finished environments' infos stay valid
+    env.close()

@@ -30,8 +30,9 @@ def main():
     for t in range(steps):
         obs, rew, dones, infos = env.step(acts[t % 8])
     dt = time.perf_counter() - t0
-    per_step_bytes = acts[0].nbytes + obs.nbytes + rew.nbytes + 2 * n + sum(
-        v.numel() * v.element_size() for k, v in env.info.items() if k not in ("episode_return", "episode_length"))
+    # actions up; observations + the head of the slab (reward, flags, done counter) down; the info words follow for finished
+    # environments only (a few rows per step; the rest on request)
+    per_step_bytes = acts[0].nbytes + obs.nbytes + env._slab_head
     print(f"numpy path: {n} envs, {1e6 * dt / steps:.1f} us/step, {n * steps / dt:.3e} env-steps/s, "
           f"{per_step_bytes / 1e6:.2f} MB over PCIe per step ({per_step_bytes * steps / dt / 1e9:.1f} GB/s)")
     # tensor API on the same handle, for the ratio
