@@ -34,4 +34,6 @@ c.reset_torch(); d.reset_torch(); d.set_rollout_fused(8)
 oc = [x.clone() for x in c.rollout_torch(tape[:64], 64)]; od = [x.clone() for x in d.rollout_torch(tape[:64], 64)]
 for x, y in zip(oc, od): assert torch.equal(x, y)
 assert bytes(c.get_state()) == bytes(d.get_state())
+import hashlib
+print("state sha256", hashlib.sha256(s0).hexdigest()[:16], hashlib.sha256(bytes(c.get_state())).hexdigest()[:16])
 print("v2dr forms agree; misses", envs[1].episode_pool_misses(), "crowded", envs[1].episode_pool_crowded())
