@@ -568,7 +568,8 @@ def main():
                        "envs_per_gpu": n, "kernel_variant": variant, "launches_per_step": 1, "form": forms[0],
                        "episode_pool": pool_info,
                        "phase": f"steady state: episodes desynchronised by {D} fused-rollout steps, then {P} + {W} untimed steps of the timed form",
-                       "sharding": f"{world} x {n} independent envs, no collective in the step"},
+                       "sharding": f"{world} x {n} independent envs, no collective in the step",
+                       "library_build": "safe (hot constants read from memory: the lint refused the product build)" if env.safe_build else "product"},
             "ranks": {"dist_world_size": dist.get_world_size() if dist is not None else 1, "backend": args.backend if dist is not None else None,
                       "per_rank_ms": per_rank_ms},
             "roofline": roof,

@@ -125,6 +125,7 @@ SYMBOLS = {
     "hlx_sizeof_env_state": (i32, []),
     "hlx_sizeof_info_soa": (i32, []),
     "hlx_abi_version": (i32, []),
+    "hlx_hot_words_from_memory": (i32, []),
     "hlx_last_error": (C.c_char_p, []),
     "hlx_version": (C.c_char_p, []),
     # include/hlx_obs.h

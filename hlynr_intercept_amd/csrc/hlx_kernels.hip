@@ -179,10 +179,21 @@ template <> struct BakedRd<int32_t> { static constexpr int32_t get(const uint32_
 template <> struct BakedRd<uint32_t> { static constexpr uint32_t get(const uint32_t* t, int off) { return t[off >> 2]; } };
 template <> struct BakedRd<double> { static constexpr double get(const uint32_t* t, int off) {
     return __builtin_bit_cast(double, (unsigned long long)t[off >> 2] | ((unsigned long long)t[(off >> 2) + 1] << 32)); } };
-template <int BAKE, typename T, int OFF> DEV T hot_get(uint32_t w0, uint32_t w1) {
+// -DHLX_HOT_FROM_MEMORY=1, the SAFE build: every hot constant is read from the parameter block in memory (uniform loads through
+// the kernel argument `P`) instead of across lanes out of two vector registers.  Slower -- a cold scalar load is 1-2 k cycles for the
+// lone wave of a SIMD, which is why the product build does not do it -- but independent of what the register allocator does with
+// those two registers: it is what hlynr_intercept_amd/build.py falls back to when hotcheck.py refuses the product build (a compiler
+// that spills a hot-word register; the review's "one ROCm upgrade away from build refused"), so that such a toolchain yields a
+// correct, slower library instead of none.  Same arithmetic, same bits (tests/test_safe_build_gpu.py).
+#ifndef HLX_HOT_FROM_MEMORY
+#define HLX_HOT_FROM_MEMORY 0
+#endif
+template <int BAKE, typename T, int OFF> DEV T hot_get(uint32_t w0, uint32_t w1, const KParams* P) {
     if constexpr (BAKE != 0 && OFF < (int)sizeof(KCfg)) {
         constexpr T v = BakedRd<T>::get(HLX_BAKED_TAB[BAKE - 1], OFF);
         return v;
+    } else if constexpr (HLX_HOT_FROM_MEMORY) {
+        return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(&P->hot) + OFF);
     } else return HotRd<T>::get(w0, w1, OFF);
 }
 // ... and the spawn / domain-randomisation constants a respawning lane needs (KCold): literals in the baked instantiations,
@@ -196,7 +207,7 @@ template <int BAKE, int OFF> DEV double cold_get(const KParams* P) {
 }
 #define COLD(path) (cold_get<BAKE, (int)offsetof(KCold, path)>(P))
 #define HOT(path) \
-    (hot_get<BAKE, std::remove_cv_t<std::remove_reference_t<decltype(((const KHot*)nullptr)->path)>>, (int)offsetof(KHot, path)>(hotw0, hotw1))
+    (hot_get<BAKE, std::remove_cv_t<std::remove_reference_t<decltype(((const KHot*)nullptr)->path)>>, (int)offsetof(KHot, path)>(hotw0, hotw1, P))
 
 // NOISE = parity-mode instantiation that can take its random draws from caller-supplied float64 buffers;
 // the production instantiation (NOISE = false) contains no trace of that path.
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
     const PoolPtrs pp2 = MODE == 2 ? pool_ptrs(arena, n, g_planes, o_planes) : PoolPtrs{};
     // Hot parameter block: two coalesced dword loads per lane now, v_readlane per constant later (hlx_kargs.h).  (The first
     // vector loads of every instantiation: hotcheck.py identifies the block's registers that way.)
-    uint32_t hotw0 = reinterpret_cast<const uint32_t*>(P)[lane], hotw1 = reinterpret_cast<const uint32_t*>(P)[64 + lane];
+    uint32_t hotw0 = HLX_HOT_FROM_MEMORY ? 0u : reinterpret_cast<const uint32_t*>(P)[lane], hotw1 = HLX_HOT_FROM_MEMORY ? 0u : reinterpret_cast<const uint32_t*>(P)[64 + lane];
     int i_ = blockIdx.x * 64 + lane;
     bool live_ = i_ < n;
     unsigned long long fill_mask = ~0ull;     // MODE 2: the lanes of this block whose entry is to be renewed

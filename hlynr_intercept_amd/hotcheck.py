@@ -54,6 +54,11 @@ def _llvm_bin():
                                + ", ".join(c for c in cands if c) + "; set HLX_LLVM_BIN")
 
 
+class HotcheckViolation(RuntimeError):
+    """The code object reloads, splits or re-uses a hot-word register: its cross-lane reads would be wrong.  build.py answers with
+    the SAFE build (constants read from memory, -DHLX_HOT_FROM_MEMORY=1)."""
+
+
 class HotcheckToolsMissing(RuntimeError):
     """The disassembler tool chain is missing: the check could not RUN (distinct from a hot-word violation)."""
 
@@ -240,7 +245,7 @@ def verify(path=None):
     if n == 0:
         raise RuntimeError("hotcheck: no hlx_env_kernel instantiation found in the code object")
     if fail:
-        raise RuntimeError("hotcheck: the register allocator spilled, split or re-used a hot-constant register "
+        raise HotcheckViolation("hotcheck: the register allocator spilled, split or re-used a hot-constant register "
                            "(v_readlane would read stale lanes): " + "; ".join(f"{k[:60]}... {r} {ops}" for k, r, ops in fail))
     return n
 

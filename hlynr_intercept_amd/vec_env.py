@@ -596,6 +596,12 @@ class HlynrVecEnv(_SB3VecEnv):
         _lib.check(self._lib.hlx_get_episode_pool_stats(self._h, C.byref(out)))
         return dict(misses=int(out[0]), full_fills=int(out[1]), partial_fills=int(out[2]), suspended_steps=int(out[3]))
 
+    @property
+    def safe_build(self) -> bool:
+        """True if the loaded library is the SAFE build (step-kernel constants read from memory: what build.py falls back to when the
+        disassembly lint refuses the product build -- same results, slower; hlx.h hlx_hot_words_from_memory)."""
+        return bool(self._lib.hlx_hot_words_from_memory())
+
     def set_load_schedule(self, mode: int):
         """-1 auto (by batch size), 0 all loads at kernel entry, 1 Kalman / ring loads behind the Philox block, 2 = 1 + the
         lone-wave schedule for at most one wave per SIMD (hlx.h)."""

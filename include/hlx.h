@@ -370,6 +370,10 @@ int32_t hlx_sizeof_info_soa(void);
  * binding can refuse a library built from another revision even where it cannot rebuild it (hlynr_intercept_amd/_lib.py). */
 #define HLX_ABI_VERSION 4
 int32_t hlx_abi_version(void);
+/* 1 if this library is the SAFE build (-DHLX_HOT_FROM_MEMORY=1: the step kernel reads its constants from the parameter block in
+ * memory instead of across lanes out of two vector registers -- what the build falls back to when the disassembly lint refuses the
+ * product build; same results, slower), 0 for the product build. */
+int32_t hlx_hot_words_from_memory(void);
 const char *hlx_last_error(void);
 const char *hlx_version(void);
 
