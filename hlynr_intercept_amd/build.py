@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.environ.get("HLX_LIBRARY") or os.path.join(_HERE, "libhlx.so")   # HLX_LIBRARY: diagnostic builds
 SOURCES = ["hlx_kernels.hip"]
-DEPS = ["hlx_kernels.hip", "hlx_host.inc", "hlx_obs.inc", "hlx_device.h", "hlx_kargs.h", "hlx_kcfg.h", "hlx_bake_gen.cpp", os.path.join("..", "..", "include", "hlx.h"),
+DEPS = ["hlx_kernels.hip", "hlx_inst_gen.h", "hlx_host.inc", "hlx_obs.inc", "hlx_device.h", "hlx_kargs.h", "hlx_kcfg.h", "hlx_bake_gen.cpp", os.path.join("..", "..", "include", "hlx.h"),
         os.path.join("..", "..", "include", "hlx_obs.h"), "hlx_hrl.inc", os.path.join("..", "..", "include", "hlx_hrl.h")]
 
 
@@ -97,6 +97,75 @@ def needs_build() -> bool:
         return any(os.path.getmtime(os.path.join(CSRC, d)) > mt for d in DEPS)
 
 
+INST_LIST = os.path.join(CSRC, "hlx_inst_gen.h")
+PARTS = 8      # translation units the step kernel's instantiations are spread over (one hipcc each, run at once)
+_INST_RE = __import__("re").compile(r"hlx_env_kernelILj(\d+)ELi(\d+)ELb([01])ELb([01])ELi(\d+)ELi(\d+)EE")
+
+
+def instantiations(text: str):
+    """The (SPEC, MODE, NOISE, PERSIST, LATE, BAKE) tuples of the step-kernel instantiations a disassembly listing names."""
+    return sorted({tuple(int(x) for x in m.groups()) for m in _INST_RE.finditer(text)})
+
+
+def write_inst_list(insts, verbose: bool = False) -> bool:
+    """csrc/hlx_inst_gen.h: which instantiation is compiled in which part.  Heavy ones first, dealt round robin: a generic (run-time
+    flags) or fused-rollout kernel takes several times as long to compile as a baked single-step one.  Committed, like
+    hlx_baked_gen.h; rewritten only when its content changes.  Returns True if it was rewritten."""
+    def weight(t):
+        spec, mode, noise, persist, late, bake = t
+        return -((4 if spec & 0x80000000 else 2 if not bake else 1) * (3 if persist else 2 if mode == 0 else 1) + (1 if noise else 0))
+    order = sorted(insts, key=lambda t: (weight(t), t))
+    lines = ["// generated by hlynr_intercept_amd/build.py from the instantiations of the last library it built: which translation-unit part",
+             "// compiles which instantiation of the step kernel (hlx_kernels.hip, \"Launchers\").  A hint about WHERE to compile, never about what",
+             "// exists: an instantiation that is not listed is compiled with the host code, as in a single translation unit."]
+    for k in range(PARTS):
+        lines.append(f"#if !defined(HLX_TU_PART) || HLX_TU_PART == {k}")
+        for spec, mode, noise, persist, late, bake in order[k::PARTS]:
+            lines.append(f"HLX_INST({spec}u, {mode}, {'true' if noise else 'false'}, {'true' if persist else 'false'}, {late}, {bake})")
+        lines.append("#endif")
+    text = "\n".join(lines) + "\n"
+    old = open(INST_LIST).read() if os.path.exists(INST_LIST) else None
+    if text == old:
+        return False
+    with open(INST_LIST, "w") as f:
+        f.write(text)
+    if verbose:
+        print("wrote", INST_LIST, f"({len(order)} instantiations in {PARTS} parts)")
+    return True
+
+
+def _listed() -> int:
+    try:
+        return open(INST_LIST).read().count("HLX_INST(")
+    except OSError:
+        return 0
+
+
+def _compile_parallel(flags, extra, out, verbose):
+    """The library from PARTS + 1 translation units compiled at once (hlx_kernels.hip, "Launchers"), linked into `out`."""
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    src = os.path.join(CSRC, SOURCES[0])
+    cflags = [f for f in flags if f != "-shared"]
+    with tempfile.TemporaryDirectory(dir=_HERE) as tmp:
+        jobs = [(os.path.join(tmp, "host.o"), ["-DHLX_TU_HOST"])] + [(os.path.join(tmp, f"part{k}.o"), [f"-DHLX_TU_PART={k}"]) for k in range(PARTS)]
+
+        def one(job):
+            obj, defs = job
+            cmd = [_hipcc()] + cflags + extra + defs + ["-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd, cwd=CSRC)
+            return obj
+
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2)))) as pool:
+            objs = list(pool.map(one, jobs))
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=CSRC)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Build (if needed) under an exclusive file lock: processes started together (pytest-xdist, several ranks without
     LOCAL_RANK, notebooks) queue up instead of compiling into the same file; the compiler writes to a name unique to this
@@ -115,6 +184,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
                      "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-Wno-unused-value"]
 
             def compile_(extra):
+                # several translation units at once when csrc/hlx_inst_gen.h says how to split the instantiations (HLX_SINGLE_TU=1:
+                # never); any failure on that path falls back to the single translation unit of rounds 1-4
+                if _listed() and not os.environ.get("HLX_SINGLE_TU"):
+                    try:
+                        _compile_parallel(flags, extra, tmp, verbose)
+                        return
+                    except Exception as why:
+                        print(f"hlynr_intercept_amd.build: parallel build failed ({why}); compiling one translation unit", flush=True)
                 cmd = [_hipcc()] + flags + extra + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
                 if verbose:
                     print(" ".join(cmd))
@@ -149,6 +226,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
             elif os.path.exists(marker):
                 os.remove(marker)
             os.replace(tmp, LIB)
+            try:      # where the NEXT build compiles what: from what this one contains (a hint file: never a reason to fail)
+                write_inst_list(instantiations(hotcheck.listing(LIB)), verbose)
+            except Exception:
+                pass
             with open(LIB + ".srchash", "w") as f:
                 f.write(_src_hash() + "\n")
             return LIB
@@ -173,10 +254,18 @@ def build_safe(force: bool = False, minimal: bool = False) -> str:
         return SAFE_LIB
     generate_baked(False)
     tmp = f"{SAFE_LIB}.{os.getpid()}.tmp"
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=16",
-           "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-Wno-unused-value"] + SAFE_FLAGS + (["-DHLX_AB_MINIMAL"] if minimal else []) + \
-          ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
-    subprocess.check_call(cmd, cwd=CSRC)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mllvm", "-amdgpu-kernarg-preload-count=16",
+             "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-Wno-unused-value"]
+    done = False
+    if not minimal and _listed() and not os.environ.get("HLX_SINGLE_TU"):
+        try:
+            _compile_parallel(flags, SAFE_FLAGS, tmp, False)
+            done = True
+        except Exception as why:
+            print(f"hlynr_intercept_amd.build: parallel build of the safe variant failed ({why}); compiling one translation unit", flush=True)
+    if not done:
+        subprocess.check_call([_hipcc()] + flags + SAFE_FLAGS + (["-DHLX_AB_MINIMAL"] if minimal else []) + ["-o", tmp] +
+                              [os.path.join(CSRC, s) for s in SOURCES], cwd=CSRC)
     os.replace(tmp, SAFE_LIB)
     with open(SAFE_LIB + ".srchash", "w") as f:
         f.write(want + "\n")

@@ -2098,9 +2098,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HLX_WAVES_PE
 
 }  // namespace
 
+// ---- Launchers: the one host-side door to an instantiation of the step kernel, and what lets the library be compiled in parallel.
+// The kernel template above has ~90 instantiations (variant x mode x load schedule x baked preset) and one translation unit compiles
+// them one after the other: three minutes.  build.py therefore compiles this file several times at once:
+//   -DHLX_TU_PART=k : the kernel code and the explicit instantiations of the launchers csrc/hlx_inst_gen.h lists for part k, nothing else;
+//   -DHLX_TU_HOST   : everything else (the C ABI, the observation pipeline, the HRL controller), with those launchers declared
+//                     `extern template` -- a launcher the list does not name is instantiated here as always, so the list is a hint about
+//                     where to compile, never about what exists (build.py regenerates it from every library it has built).
+// Neither macro: the single translation unit of rounds 1-4 (A/B builds, fallback).  The kernels stay in the unnamed namespace: their
+// names, and everything hotcheck.py and the tools read off the code objects, are the same in all three forms.
+namespace hlx_launchers {
+struct StepArgs {
+    float4* arena; const KParams* P; const float* actions; unsigned long long t, seed; long long env_offset; int n; uint32_t slots;
+    float* obs; float* reward; uint8_t* term; uint8_t* trunc; float radius, cos_half_beam, on_rel, g_rel; int T, out_slot0, out_slots;
+};
+template <uint32_t SPEC, int MODE, bool NOISE, bool PERSIST, int LATE, int BAKE>
+void hlx_launch(dim3 grid, hipStream_t s, const StepArgs& a) {
+    hipLaunchKernelGGL((hlx_env_kernel<SPEC, MODE, NOISE, PERSIST, LATE, BAKE>), grid, dim3(64), 0, s, a.arena, a.P, a.actions, a.t, a.seed,
+                       a.env_offset, a.n, a.slots, a.obs, a.reward, a.term, a.trunc, a.radius, a.cos_half_beam, a.on_rel, a.g_rel, a.T,
+                       a.out_slot0, a.out_slots);
+}
+}  // namespace hlx_launchers
+
+#if defined(HLX_TU_PART)
+#define HLX_INST(S, M, N, P_, L, B) template void hlx_launchers::hlx_launch<S, M, N, P_, L, B>(dim3, hipStream_t, const hlx_launchers::StepArgs&);
+#include "hlx_inst_gen.h"
+#undef HLX_INST
+#else
+#if defined(HLX_TU_HOST)
+#define HLX_INST(S, M, N, P_, L, B) extern template void hlx_launchers::hlx_launch<S, M, N, P_, L, B>(dim3, hipStream_t, const hlx_launchers::StepArgs&);
+#include "hlx_inst_gen.h"
+#undef HLX_INST
+#endif
 // host side of the C ABI
 #include "hlx_host.inc"
 // on-device VecFrameStack + VecNormalize behind the step (include/hlx_obs.h)
 #include "hlx_obs.inc"
 // on-device HRL controller logic (include/hlx_hrl.h)
 #include "hlx_hrl.inc"
+#endif

@@ -73,13 +73,28 @@ def listing(path=None):
         return open(path).read()
     global LLVM_BIN
     LLVM_BIN = LLVM_BIN or _llvm_bin()
+    return "\n".join(subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", "--no-show-raw-insn", co], check=True,
+                                    capture_output=True, text=True).stdout for co in code_objects(path))
+
+
+def code_objects(path):
+    """The gfx950 code objects of a library, as files.  A library linked from several translation units (build.py compiles the
+    step kernel's instantiations in parallel) carries one offload bundle per unit, back to back in `.hip_fatbin`."""
+    global LLVM_BIN
+    LLVM_BIN = LLVM_BIN or _llvm_bin()
     tmp = tempfile.mkdtemp()
-    fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "gfx950.co")
+    fat = os.path.join(tmp, "fat.bin")
     subprocess.run([os.path.join(LLVM_BIN, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, path], check=True)
-    subprocess.run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
-                    "--input=" + fat, "--output=" + co, "--unbundle"], check=True)
-    return subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", "--no-show-raw-insn", co], check=True,
-                          capture_output=True, text=True).stdout
+    blob, magic, out = open(fat, "rb").read(), b"__CLANG_OFFLOAD_BUNDLE__", []
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)] or [0]
+    for k, (lo, hi) in enumerate(zip(starts, starts[1:] + [len(blob)])):
+        part, co = os.path.join(tmp, f"fat{k}.bin"), os.path.join(tmp, f"gfx950_{k}.co")
+        with open(part, "wb") as f:
+            f.write(blob[lo:hi])
+        subprocess.run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                        "--input=" + part, "--output=" + co, "--unbundle"], check=True)
+        out.append(co)
+    return out
 
 
 def regs(operand):

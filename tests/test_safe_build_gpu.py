@@ -79,6 +79,7 @@ def test_build_falls_back_to_the_safe_variant_when_the_lint_refuses(monkeypatch,
     monkeypatch.setattr(build.subprocess, "check_call", fake_compile)
     monkeypatch.setattr(hotcheck, "verify", fake_verify)
     monkeypatch.delenv("HLX_SAFE_BUILD", raising=False)
+    monkeypatch.setenv("HLX_SINGLE_TU", "1")          # (one compiler call per library: the parallel path is test_parallel_build... below)
     assert build.build(force=True) == lib
     assert len(calls) == 2 and "-DHLX_HOT_FROM_MEMORY=1" not in calls[0] and "-DHLX_HOT_FROM_MEMORY=1" in calls[1]
     assert os.path.exists(lib) and os.path.exists(lib + ".safe") and os.path.exists(lib + ".rejected") and os.path.exists(lib + ".srchash")
@@ -86,3 +87,41 @@ def test_build_falls_back_to_the_safe_variant_when_the_lint_refuses(monkeypatch,
     monkeypatch.setattr(hotcheck, "verify", lambda path=None: 1)
     calls.clear()
     assert build.build(force=True) == lib and len(calls) == 1 and not os.path.exists(lib + ".safe")
+
+
+def test_parallel_build_splits_the_instantiations_and_falls_back_to_one_translation_unit(monkeypatch, tmp_path):
+    """build.py's parallel path, no compiler involved: one host unit + PARTS part units compiled with the TU macros and linked; a
+    failure there is answered with the single translation unit; the list of instantiations is a pure function of a listing."""
+    from hlynr_intercept_amd import build, hotcheck
+    lib = str(tmp_path / "libhlx.so")
+    calls = []
+
+    def fake(cmd, cwd=None):
+        calls.append(cmd)
+        open(cmd[cmd.index("-o") + 1], "w").write("x")
+
+    monkeypatch.setattr(build, "LIB", lib)
+    monkeypatch.setattr(build, "generate_baked", lambda verbose=False: "")
+    monkeypatch.setattr(build.subprocess, "check_call", fake)
+    monkeypatch.setattr(hotcheck, "verify", lambda path=None: 1)
+    monkeypatch.delenv("HLX_SINGLE_TU", raising=False)
+    monkeypatch.delenv("HLX_SAFE_BUILD", raising=False)
+    assert build._listed() >= 80                                   # the committed hint file names the shipped instantiations
+    assert build.build(force=True) == lib
+    units = [c for c in calls if "-c" in c]
+    assert len(units) == build.PARTS + 1 and sum("-DHLX_TU_HOST" in c for c in units) == 1
+    assert sorted(d for c in units for d in c if d.startswith("-DHLX_TU_PART=")) == sorted(f"-DHLX_TU_PART={k}" for k in range(build.PARTS))
+    assert len(calls) == build.PARTS + 2 and "-shared" in calls[-1] and all("-shared" not in c for c in units)
+    # a compiler that fails on the split units: one translation unit, as in rounds 1-4
+    calls.clear()
+
+    def flaky(cmd, cwd=None):
+        calls.append(cmd)
+        if any(d.startswith("-DHLX_TU_PART=") for d in cmd):
+            raise build.subprocess.CalledProcessError(1, cmd)
+        open(cmd[cmd.index("-o") + 1], "w").write("x")
+
+    monkeypatch.setattr(build.subprocess, "check_call", flaky)
+    assert build.build(force=True) == lib and "-shared" in calls[-1] and not any(d.startswith("-DHLX_TU") for d in calls[-1])
+    text = "<_ZN12_GLOBAL__N_114hlx_env_kernelILj608ELi0ELb0ELb0ELi2ELi1EEEvP>:\n<_ZN12_GLOBAL__N_114hlx_env_kernelILj639ELi1ELb1ELb0ELi0ELi0EEEvP>:"
+    assert build.instantiations(text) == [(608, 0, 0, 0, 2, 1), (639, 1, 1, 0, 0, 0)]

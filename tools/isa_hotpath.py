@@ -16,14 +16,8 @@ from hlynr_intercept_amd import hotcheck      # noqa: E402
 def disassemble(path):
     """{symbol: [(address, text)]} of every hlx_env_kernel instantiation (llvm-objdump with addresses)."""
     import subprocess
-    import tempfile
-    hotcheck.LLVM_BIN = hotcheck.LLVM_BIN or hotcheck._llvm_bin()
-    tmp = tempfile.mkdtemp()
-    fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "gfx950.co")
-    subprocess.run([os.path.join(hotcheck.LLVM_BIN, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, path], check=True)
-    subprocess.run([os.path.join(hotcheck.LLVM_BIN, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
-                    "--input=" + fat, "--output=" + co, "--unbundle"], check=True)
-    txt = subprocess.run([os.path.join(hotcheck.LLVM_BIN, "llvm-objdump"), "-d", co], check=True, capture_output=True, text=True).stdout
+    txt = "\n".join(subprocess.run([os.path.join(hotcheck.LLVM_BIN or hotcheck._llvm_bin(), "llvm-objdump"), "-d", co], check=True,
+                                   capture_output=True, text=True).stdout for co in hotcheck.code_objects(path))
     out, cur = {}, None
     for line in txt.split("\n"):
         m = re.match(r"^([0-9a-f]+) <(\S+)>:", line)
